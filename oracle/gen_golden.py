@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref/librtk_ref.so).
+
+TEST INFRASTRUCTURE. Runs only in the build container, where /root/reference exists:
+the reference's own rtk_trace_ray (rtk.c:543-577, compiled verbatim by oracle/Makefile)
+is driven through the "leaf chain" of SURVEY.md section 8c -- the triangle list is cut
+into chunks of 60, each chunk becomes a minimal single-leaf blob, and every ray visits
+every blob in order with ray.max_t = best.t. All hit decisions and all t/u/v values in
+the fixtures therefore come from the reference's code, not from the restatement.
+
+Fixtures hold data only: seeds/inputs (or their SHA-256) and expected hit records.
+
+    python3 oracle/gen_golden.py [--only cfg1,edge,...] [--cfg5-rays N]
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle as po  # noqa: E402
+from rtk_amd import synth  # noqa: E402
+from rtk_amd.types import RAY_DTYPE, RTK_INF  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def compact(hits, mask):
+    return dict(hit_mask=mask.astype(np.uint8),
+                hit_mesh=np.where(mask, hits["mesh_index"], 0xFFFFFFFF).astype(np.uint32),
+                hit_tri=np.where(mask, hits["triangle_index"], 0xFFFFFFFF).astype(np.uint32),
+                hit_t=np.where(mask, hits["t"], 0).astype(np.float32),
+                hit_u=np.where(mask, hits["u"], 0).astype(np.float32),
+                hit_v=np.where(mask, hits["v"], 0).astype(np.float32))
+
+
+def save(name, **kw):
+    path = os.path.join(GOLDEN, name)
+    np.savez_compressed(path, **kw)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def chain_reference(tris, rays, mesh_index=None, triangle_index=None):
+    blobs = po.leaf_chain_blobs(tris.reshape(-1, 3, 3), mesh_index, triangle_index)
+    t0 = time.time()
+    hits, mask = po.ref_trace_chain(blobs, rays)
+    print("  reference leaf chain: %d rays x %d blobs in %.1f s, %d hits"
+          % (len(rays), len(blobs), time.time() - t0, int(mask.sum())))
+    return hits, mask
+
+
+def gen_cfg1():
+    tris = synth.scene_for_config(1)
+    rays = synth.rays_config1(65536)
+    hits, mask = chain_reference(tris, rays)
+    save("cfg1_full.npz", scene_sha256=sha(tris), rays_sha256=sha(rays), **compact(hits, mask))
+
+
+def sample_indices(total, count, mult=4099):
+    return ((np.arange(count, dtype=np.int64) * mult) % total).astype(np.int64)
+
+
+def gen_cfg2(tris):
+    idx = sample_indices(4096 * 4096, 4096)
+    allr = np.concatenate([synth.rays_pinhole(first=int(i), count=1) for i in idx])
+    hits, mask = chain_reference(tris, allr)
+    save("cfg2_sample.npz", scene_sha256=sha(tris), ray_index=idx, rays_sha256=sha(allr), **compact(hits, mask))
+
+
+def gen_cfg3(tris):
+    rays = synth.rays_incoherent(4096)
+    hits, mask = chain_reference(tris, rays)
+    save("cfg3_sample.npz", scene_sha256=sha(tris), rays_sha256=sha(rays), **compact(hits, mask))
+
+
+def gen_cfg5(nrays):
+    tris = synth.scene_for_config(5)
+    rays = synth.rays_shadow(nrays)
+    hits, mask = chain_reference(tris, rays)
+    # config 5 is any-hit: the golden value is the boolean; the closest hit is kept too
+    save("cfg5_sample.npz", scene_sha256=sha(tris), rays_sha256=sha(rays), **compact(hits, mask))
+
+
+def edge_scene():
+    """Small hand-made scene; every coordinate is exactly representable."""
+    T = []
+    M = []
+    def tri(a, b, c, mesh=0):
+        T.append([a, b, c]); M.append(mesh)
+    tri((0, 0, 1), (1, 0, 1), (0, 1, 1))                 # 0: axis-aligned, z = 1
+    tri((1, 0, 1), (1, 1, 1), (0, 1, 1))                 # 1: shares the diagonal with 0
+    tri((0, 0, 2), (1, 0, 2), (0, 1, 2))                 # 2: behind 0
+    tri((.25, .25, .5), (.25, .25, .5), (.375, .375, .5))  # 3: zero area, in front of 0
+    tri((2, 0, 0), (3, 0, 1), (2, 1, 2))                 # 4: slanted
+    tri((4, 0, 1), (4, 1, 1), (5, 0, 1))                 # 5: opposite winding
+    tri((6, 0, 1), (7, 0, 1), (6, 1, 1))                 # 6: next to 7 along x
+    tri((7, 0, 1), (8, 0, 1), (7, 1, 1))                 # 7: touches 6 in one vertex
+    tri((0, 0, 1), (1, 0, 1), (0, 1, 1), mesh=1)         # 8: exact duplicate of 0 in mesh 1
+    tri((0, 0, 1), (1, 0, 1), (0, 1, 1), mesh=1)         # 9: and again
+    tris = np.array(T, dtype=np.float32)
+    mesh = np.array(M, dtype=np.uint32)
+    # triangle_index counts inside each mesh (reference rtk.c:1168-1169)
+    tri_index = np.zeros(len(T), np.uint32)
+    for m in np.unique(mesh):
+        sel = mesh == m
+        tri_index[sel] = np.arange(sel.sum(), dtype=np.uint32)
+    return tris, mesh, tri_index
+
+
+def edge_rays():
+    R = []
+    def ray(o, d, tmin=0.0, tmax=float(RTK_INF)):
+        R.append((o, d, tmin, tmax))
+    nz = -0.0
+    ray((.25, .25, 0), (0, 0, 1))                 # interior, two zero direction components
+    ray((.5, .5, 0), (0, 0, 1))                   # exactly on the shared diagonal (f64 fallback, tie 0/1)
+    ray((1, 0, 0), (0, 0, 1))                     # through a vertex shared by 0 and 1
+    ray((0, 0, 0), (0, 0, 1))                     # through the corner vertex of 0
+    ray((0, .5, 0), (0, 0, 1))                    # on an outer edge of 0
+    ray((1.0000001, 0, 0), (0, 0, 1))             # just outside
+    ray((-1e-7, .5, 0), (0, 0, 1))                # just outside the outer edge
+    ray((.25, .25, 0), (nz, 0.0, 1))              # negative zero in the direction
+    ray((.25, .25, 0), (nz, nz, 1))
+    ray((.25, .25, 1.5), (0, 0, 1))               # starts between 0 and 2
+    ray((.25, .25, 0), (0, 0, 1), tmin=1.0)       # t == min_t is rejected (open interval)
+    ray((.25, .25, 0), (0, 0, 1), tmax=1.0)       # t == max_t is rejected
+    ray((.25, .25, 0), (0, 0, 1), tmax=2.0)
+    ray((.25, .25, 0), (0, 0, 1), tmin=0.999999, tmax=1.000001)
+    ray((.25, .25, 0), (0, 0, 2))                 # unnormalised direction: t = 0.5
+    ray((.25, .25, 0), (0, 0, .5))
+    ray((.25, .25, 3), (0, 0, -1))                # from behind: hits 2 first
+    ray((.3, .3, 0), (0, 0, 1))                   # passes the zero-area triangle 3
+    ray((.25, .25, 0), (.01, .02, 1))
+    ray((-1, .25, 1), (1, 0, 0))                  # in the plane of 0: det == 0
+    ray((2.25, .25, -1), (0, 0, 1))               # slanted 4
+    ray((2.25, .25, 3), (0, 0, -1))               # slanted 4 from the other side
+    ray((1, -1, -1), (1, 1, 1))                   # |dx|=|dy|=|dz|: kz = x
+    ray((2.5, -1, -1), (0, 1, 1))                 # |dy|=|dz|: kz = y
+    ray((2.5, -1, -1), (0, -1, -1))
+    ray((4.25, .25, 0), (0, 0, 1))                # opposite winding, front
+    ray((4.25, .25, 2), (0, 0, -1))               # opposite winding, back
+    ray((7, 0, 0), (0, 0, 1))                     # vertex shared by 6 and 7
+    ray((7, .5, 0), (0, 0, 1))                    # edge of 7 only
+    ray((6.5, .5, 0), (0, 0, 1))                  # hypotenuse of 6
+    ray((.25, .25, 0), (0, 0, 1e-30))             # tiny direction
+    ray((.25, .25, 0), (0, 0, 1e30))              # huge direction
+    ray((.25, .25, -1e6), (0, 0, 1))              # far origin
+    ray((100, 100, 0), (0, 0, 1))                 # misses everything
+    ray((.25, .25, 0), (1, 0, 0))                 # parallel, misses
+    out = np.zeros(len(R), dtype=RAY_DTYPE)
+    for i, (o, d, a, b) in enumerate(R):
+        out[i]["origin"] = o; out[i]["direction"] = d; out[i]["min_t"] = a; out[i]["max_t"] = b
+    # plus deterministic pseudo-random rays over the same scene
+    n = 512
+    u = synth.u01(77, 0, n * 6).reshape(n, 6)
+    rnd = np.zeros(n, dtype=RAY_DTYPE)
+    rnd["origin"][:, 0] = u[:, 0] * np.float32(9.0) - np.float32(0.5)
+    rnd["origin"][:, 1] = u[:, 1] * np.float32(2.0) - np.float32(0.5)
+    rnd["origin"][:, 2] = np.float32(-1.0)
+    rnd["direction"][:, 0] = (u[:, 3] - np.float32(0.5))
+    rnd["direction"][:, 1] = (u[:, 4] - np.float32(0.5))
+    rnd["direction"][:, 2] = np.float32(1.0)
+    rnd["min_t"] = 0
+    rnd["max_t"] = RTK_INF
+    # a grid of axis-parallel rays landing exactly on lattice points (edges/vertices/diagonal)
+    g = []
+    for ix in range(0, 17):
+        for iy in range(0, 17):
+            g.append(((ix / 16.0, iy / 16.0, 0.0), (0, 0, 1), 0.0, float(RTK_INF)))
+    grid = np.zeros(len(g), dtype=RAY_DTYPE)
+    for i, (o, d, a, b) in enumerate(g):
+        grid[i]["origin"] = o; grid[i]["direction"] = d; grid[i]["min_t"] = a; grid[i]["max_t"] = b
+    return np.concatenate([out, rnd, grid])
+
+
+def gen_edge():
+    tris, mesh, tri_index = edge_scene()
+    rays = edge_rays()
+    blobs = po.leaf_chain_blobs(tris, mesh, tri_index)
+    assert len(blobs) == 1
+    hits, mask = po.ref_trace_chain(blobs, rays, threads=1)
+    print("  edge cases: %d rays, %d hits" % (len(rays), int(mask.sum())))
+    save("edge_cases.npz", tris=tris, mesh=mesh, tri_index=tri_index, rays=rays.view(np.float32).reshape(-1, 8),
+         **compact(hits, mask))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="edge,cfg1,cfg2,cfg3,cfg5")
+    ap.add_argument("--cfg5-rays", type=int, default=1024)
+    a = ap.parse_args()
+    if not po.have_ref():
+        po.build_oracle()
+    if not po.have_ref():
+        sys.exit("oracle/_ref/librtk_ref.so missing: this script needs the reference (build container only)")
+    os.makedirs(GOLDEN, exist_ok=True)
+    only = set(a.only.split(","))
+    if "edge" in only:
+        gen_edge()
+    if "cfg1" in only:
+        gen_cfg1()
+    if only & {"cfg2", "cfg3"}:
+        tris = synth.scene_for_config(2)
+        if "cfg2" in only:
+            gen_cfg2(tris)
+        if "cfg3" in only:
+            gen_cfg3(tris)
+    if "cfg5" in only:
+        gen_cfg5(a.cfg5_rays)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""Deterministic synthetic scenes and ray batches of BASELINE.json's configs.
+
+Counter-based generator: value k of stream `seed` is
+splitmix64((seed << 40) + k); its top 24 bits times 2^-24 is a float32 in [0,1) that is
+exact, and every later operation is one correctly rounded float32 add/mul, so numpy here
+and any C/HIP restatement produce bit-identical inputs.
+"""
+import numpy as np
+
+from .types import RAY_DTYPE, RTK_INF
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def u01(seed, first, count):
+    """float32 U[0,1) values number first..first+count-1 of stream `seed`."""
+    k = np.arange(first, first + count, dtype=np.uint64)
+    h = splitmix64((np.uint64(seed) << np.uint64(40)) + k)
+    return ((h >> np.uint64(40)).astype(np.float32)) * np.float32(2.0 ** -24)
+
+
+def triangle_soup(num_tris, spread, seed=1, chunk=1 << 20):
+    """Unindexed float32 mesh [3*num_tris, 3]: centre ~U[0,1)^3, vertex = centre + spread*(U-0.5)."""
+    out = np.empty((num_tris, 3, 3), dtype=np.float32)
+    sp = np.float32(spread)
+    for a in range(0, num_tris, chunk):
+        n = min(chunk, num_tris - a)
+        u = u01(seed, a * 12, n * 12).reshape(n, 12)
+        centre = u[:, 0:3]
+        off = (u[:, 3:12] - np.float32(0.5)) * sp
+        out[a:a + n] = centre[:, None, :] + off.reshape(n, 3, 3)
+    return out.reshape(num_tris * 3, 3)
+
+
+def _rays(n):
+    r = np.zeros(n, dtype=RAY_DTYPE)
+    r["min_t"] = np.float32(0.0)
+    r["max_t"] = RTK_INF
+    return r
+
+
+def rays_config1(n=65536, seed=2):
+    """origin (U,U,-1), direction (0.3(U-.5), 0.3(U-.5), 1)."""
+    u = u01(seed, 0, n * 4).reshape(n, 4)
+    r = _rays(n)
+    r["origin"][:, 0] = u[:, 0]
+    r["origin"][:, 1] = u[:, 1]
+    r["origin"][:, 2] = np.float32(-1.0)
+    r["direction"][:, 0] = np.float32(0.3) * (u[:, 2] - np.float32(0.5))
+    r["direction"][:, 1] = np.float32(0.3) * (u[:, 3] - np.float32(0.5))
+    r["direction"][:, 2] = np.float32(1.0)
+    return r
+
+
+def rays_pinhole(width=4096, height=4096, first=0, count=None, jitter=(0.5, 0.5)):
+    """Row-major pinhole frame from (0.5,0.5,-1.5), fov factor 0.7 (config 2)."""
+    total = width * height
+    if count is None:
+        count = total - first
+    i = np.arange(first, first + count, dtype=np.int64)
+    x = (i % width).astype(np.float32)
+    y = (i // width).astype(np.float32)
+    r = _rays(count)
+    r["origin"][:] = np.array([0.5, 0.5, -1.5], dtype=np.float32)
+    jx, jy = np.float32(jitter[0]), np.float32(jitter[1])
+    r["direction"][:, 0] = ((x + jx) / np.float32(width) - np.float32(0.5)) * np.float32(0.7)
+    r["direction"][:, 1] = ((y + jy) / np.float32(height) - np.float32(0.5)) * np.float32(0.7)
+    r["direction"][:, 2] = np.float32(1.0)
+    return r
+
+
+def frame_jitter(frame, seed=4):
+    """Sub-pixel offset of frame `frame` of config 4; frame 0 is config 2 itself."""
+    if frame == 0:
+        return (0.5, 0.5)
+    u = u01(seed, 2 * frame, 2)
+    return (float(u[0]), float(u[1]))
+
+
+def rays_incoherent(n, seed=3, first=0):
+    """origin ~U[-0.5,1.5)^3, direction = target ~U[0,1)^3 minus origin (config 3)."""
+    u = u01(seed, first * 6, n * 6).reshape(n, 6)
+    r = _rays(n)
+    o = u[:, 0:3] * np.float32(2.0) - np.float32(0.5)
+    r["origin"] = o
+    r["direction"] = u[:, 3:6] - o
+    return r
+
+
+def rays_shadow(n, seed=5, first=0, light=(0.5, 2.0, 0.5)):
+    """origin ~U[0,1)^3, direction = light - origin, t in (1e-4, 1) (config 5)."""
+    u = u01(seed, first * 3, n * 3).reshape(n, 3)
+    r = _rays(n)
+    r["origin"] = u
+    r["direction"] = np.array(light, dtype=np.float32)[None, :] - u
+    r["min_t"] = np.float32(1e-4)
+    r["max_t"] = np.float32(1.0)
+    return r
+
+
+CONFIGS = {
+    1: dict(num_tris=10_000, spread=0.05, scene_seed=1),
+    2: dict(num_tris=1_000_000, spread=0.02, scene_seed=1),
+    3: dict(num_tris=1_000_000, spread=0.02, scene_seed=1),
+    4: dict(num_tris=1_000_000, spread=0.02, scene_seed=1),
+    5: dict(num_tris=10_000_000, spread=0.01, scene_seed=1),
+}
+
+
+def scene_for_config(cfg):
+    c = CONFIGS[cfg]
+    return triangle_soup(c["num_tris"], c["spread"], c["scene_seed"])
