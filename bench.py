@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s, primary closest-hit rays on the 1M-triangle scene.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch: every rank traces its own 4096x4096
+frame (2^24 rays; N=1 is BASELINE.json configs[1], N>1 is configs[3]: frame r on rank r,
+BVH replicated) and, for N>1, the 16-byte hit records are gathered onto rank 0 over RCCL.
+Rays, BVH and hit records are resident in HBM for the whole timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job Mrays/s, plus
+  roofline:     algorithmic bytes of the traversal kernel / its measured duration vs 8 TB/s
+  cpu_baseline: the CPU oracle (a port of rtk.c's trace path) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 32, 16
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="coherent", choices=["coherent", "incoherent"])
+    ap.add_argument("--bvh", default="device", choices=["device", "oracle-blob"],
+                    help="device = GPU LBVH build (product path); oracle-blob = upload a blob built by the CPU oracle (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave hit records on their GPU")
+    ap.add_argument("--static", action="store_true", help="A/B: one fixed ray per lane instead of persistent refill")
+    ap.add_argument("--no-tiling", action="store_true")
+    ap.add_argument("--refill-min", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--frame", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from rtk_amd import api, shard, synth
+    from rtk_amd.types import HIT_RECORD_DTYPE
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    api.lib().rtk_amd_set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W = H = args.frame
+    n = W * H
+    cfg = synth.CONFIGS[2]
+
+    # ---- scene: replicated on every rank -------------------------------------------------
+    t0 = time.time()
+    tris = synth.triangle_soup(cfg["num_tris"], cfg["spread"], cfg["scene_seed"])
+    t_gen = time.time() - t0
+    t0 = time.time()
+    oracle_blob = None
+    if args.bvh == "device":
+        ds = api.DeviceScene.build([dict(positions=tris)])
+        bvh_kind = "gpu-lbvh"
+    else:
+        from oracle import pyoracle
+        oracle_blob = pyoracle.build_scene([dict(positions=tris)])
+        ds = api.DeviceScene.upload(oracle_blob)
+        bvh_kind = "oracle-sah-blob-upload"
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    info = ds.info()
+    if rank == 0:
+        log("scene: %d tris generated in %.2fs, bvh (%s) in %.2fs: %s" % (cfg["num_tris"], t_gen, bvh_kind, t_build, info))
+
+    # ---- rays: frame `rank` of config 4 (frame 0 == config 2) ------------------------------
+    if args.workload == "coherent":
+        rays = synth.rays_pinhole(W, H, jitter=synth.frame_jitter(rank))
+        opts = api.make_opts(image=None if args.no_tiling else (W, H), static=args.static,
+                             refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu)
+        workload = "config2: 1M-tri soup (seed 1, spread 0.02), %dx%d coherent pinhole primary rays" % (W, H)
+    else:
+        rays = synth.rays_incoherent(n, first=rank * n)
+        opts = api.make_opts(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu)
+        workload = "config3: 1M-tri soup, %d incoherent rays" % n
+    d_rays = api.to_device(rays)
+    d_rec = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device="cuda")
+    sizes = [n * HIT_BYTES] * world
+
+    def step():
+        ds.trace_device(d_rays, n, d_rec, opts)
+        if world > 1 and not args.no_gather:
+            return shard.gather_records(d_rec, sizes, dst=0)
+        return d_rec
+
+    # ---- algorithmic bytes from the counting build (not timed) ----------------------------
+    _, ctr = ds.trace_counted(rays, opts)
+    alg_bytes = n * (RAY_BYTES + HIT_BYTES) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region --------------------------------------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()                       # same stream the kernel is launched on
+        ds.trace_device(d_rays, n, d_rec, opts)
+        ev[k][1].record()
+        if world > 1 and not args.no_gather:
+            shard.gather_records(d_rec, sizes, dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- sanity of the result that was timed ---------------------------------------------
+    rec = d_rec.cpu().numpy().view(HIT_RECORD_DTYPE)
+    hit_frac = float((rec["prim"] != 0xFFFFFFFF).mean())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_rays = n * world * args.steps
+    mrays = total_rays / elapsed / 1e6
+    k_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Mrays/sec (primary, closest-hit) on 1M-tri scene",
+        "value": round(mrays, 2),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload, "rays_per_gpu_per_step": n, "bvh": bvh_kind, "bvh_nodes": info["num_nodes"],
+                   "bvh_build_s": round(t_build, 3), "hit_fraction": round(hit_frac, 4),
+                   "gather": bool(world > 1 and not args.no_gather), "launch": "static" if args.static else "persistent",
+                   "parallelism": "ray-batch shards x%d, BVH replicated" % world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "rtk_trace_kernel<0,false>", "kernel_ms": round(k_ms, 4),
+                     "algorithmic_bytes_per_ray": round(alg_bytes / n, 1),
+                     "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
+                                        "triangles": round(ctr["triangles"] / n, 2)},
+                     "kernel_mrays_s": round(n / (k_ms * 1e-3) / 1e6, 1)},
+    }
+
+    # ---- CPU baseline: the oracle (a port of rtk.c's trace path) on this host's cores -----
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        t0 = time.time()
+        if oracle_blob is None:
+            oracle_blob = pyoracle.build_scene([dict(positions=tris)])
+        t_cpu_build = time.time() - t0
+        threads = pyoracle.default_threads()
+        # bounded sample: every k-th ray of the same batch (a prefix would be all top-of-frame misses)
+        probe_sel = np.arange(0, n, max(1, n >> 17))
+        t0 = time.time()
+        pyoracle.trace(oracle_blob, rays[probe_sel], threads=threads)
+        rate = len(probe_sel) / max(time.time() - t0, 1e-6)
+        stride = 1
+        while n // stride > rate * args.cpu_seconds and stride < n:
+            stride *= 2
+        sel = np.arange(0, n, stride)
+        sample = len(sel)
+        sample_rays = rays if stride == 1 else np.ascontiguousarray(rays[sel])
+        t0 = time.time()
+        ohits, omask = pyoracle.trace(oracle_blob, sample_rays, threads=threads)
+        dt = time.time() - t0
+        t0 = time.time()
+        pyoracle.trace(oracle_blob, rays[probe_sel], threads=1)
+        rate1 = len(probe_sel) / max(time.time() - t0, 1e-6)
+        # parity of the timed GPU result against the same CPU run (ids exact, t to 1e-5)
+        g = rec[sel]
+        gm = g["prim"] != 0xFFFFFFFF
+        mask_ok = bool((gm == omask).all())
+        both = gm & omask
+        id_mismatch = int((g["prim"][both] != ohits["triangle_index"][both]).sum()) + int((gm != omask).sum())
+        ids_ok = mask_ok and id_mismatch == 0
+        rel = float(np.max(np.abs(g["t"][both] - ohits["t"][both]) / np.abs(ohits["t"][both]))) if both.any() else 0.0
+        bit_exact = float(np.mean((g["t"][both] == ohits["t"][both]) & (g["u"][both] == ohits["u"][both]) &
+                                  (g["v"][both] == ohits["v"][both]))) if both.any() else 1.0
+        out["cpu_baseline"] = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": "%d rays = every %d-th ray of the same batch, oracle SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"
+                                         % (sample, stride, t_cpu_build, threads, rate1 / 1e6),
+                               "host_cpus": os.cpu_count(),
+                               "parity_vs_gpu": {"rays": sample, "ids_exact": ids_ok, "id_mismatches": id_mismatch,
+                                                 "max_rel_t": rel, "tuv_bit_exact_fraction": bit_exact,
+                                                 "same_bvh": bool(args.bvh == "oracle-blob")}}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/*
+ * rtk_amd.h -- additive batch / device entry points of librtk_amd.so (MI355X, gfx950).
+ *
+ * The reference's trace call is per ray and synchronous (reference rtk.h:129-130,
+ * rtk.c:543-577); a GPU needs whole batches and device residency. Everything here is
+ * NEW surface next to the nine unchanged rtk.h symbols. All functions are plain C:
+ * pointers + sizes, no C++ or torch types. `stream` arguments are a hipStream_t passed
+ * as void* (NULL = the default stream); "d_" pointers are DEVICE memory.
+ *
+ * Which reference interface each entry point stands in for:
+ *   rtk_dev_scene_upload   : the hand-over of a built scene blob to the tracer. In the
+ *                            reference that is just the rtk_scene* itself (rtk.c:546);
+ *                            here the blob (format: SURVEY.md appendix A, reader
+ *                            rtk.c:181-193, 457-465) is validated and re-laid-out in HBM.
+ *   rtk_dev_scene_build    : rtk_build_scene / rtk_start_build..rtk_finish_build
+ *                            (rtk.h:119-126; rtk.c:1625-1792) with the result left
+ *                            device-resident (LBVH on the GPU instead of binned SAH tasks).
+ *   rtk_dev_scene_export   : rtk_finish_build_to (rtk.h:123; rtk.c:1732-1774): emits the
+ *                            device BVH as a reference-format blob.
+ *   rtk_dev_trace_rays     : a loop of rtk_trace_ray over a ray array (rtk.h:129).
+ *   rtk_dev_trace_rays_any : a loop of rtk_trace_ray_filter with a filter that accepts
+ *                            the first candidate (rtk.h:117, 130; stub at rtk.c:579-582).
+ *   rtk_dev_expand_hits    : the *hit = rt.hit copy-out of rtk.c:571-573 (full rtk_hit).
+ *   rtk_trace_rays         : host-pointer convenience over the three above.
+ */
+#ifndef RTK_AMD_H
+#define RTK_AMD_H
+
+#include "rtk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes (0 = success). rtk_amd_last_error() describes the last failure on the
+ * calling thread. */
+enum {
+	RTK_AMD_OK = 0,
+	RTK_AMD_ERR_NO_DEVICE = -1,   /* no HIP device / driver */
+	RTK_AMD_ERR_BAD_ARG = -2,
+	RTK_AMD_ERR_OOM = -3,
+	RTK_AMD_ERR_HIP = -4,         /* a HIP runtime call failed */
+	RTK_AMD_ERR_BAD_SCENE = -5,   /* blob failed validation */
+	RTK_AMD_ERR_UNSUPPORTED = -6,
+};
+
+const char *rtk_amd_last_error(void);
+int rtk_amd_device_count(void);
+int rtk_amd_set_device(int device);
+
+/* Device-resident scene. */
+typedef struct rtk_dev_scene rtk_dev_scene;
+
+/* Compact hit record, 16 bytes. prim is the GLOBAL primitive id: the triangle's position
+ * in concatenated mesh order (mesh_base[mesh_index] + triangle_index, cf. rtk.c:1131-1178);
+ * RTK_PRIM_NONE on a miss (then t = ray.max_t, u = v = 0). u, v as in rtk_hit. */
+typedef struct rtk_hit_record {
+	float t, u, v;
+	uint32_t prim;
+} rtk_hit_record;
+#define RTK_PRIM_NONE 0xffffffffu
+
+typedef struct rtk_dev_scene_info {
+	uint64_t num_triangles;
+	uint64_t num_meshes;
+	uint64_t num_nodes;        /* 4-wide nodes, 128 B each */
+	uint64_t node_bytes;
+	uint64_t triangle_bytes;   /* 48 B per triangle */
+	uint64_t total_device_bytes;
+	uint32_t max_depth;        /* deepest 4-wide node level (root = 1) */
+	uint32_t stack_entries;    /* traversal stack entries a ray can need */
+} rtk_dev_scene_info;
+
+/* Trace options; pass NULL for defaults. */
+typedef struct rtk_trace_opts {
+	uint32_t struct_size;      /* sizeof(rtk_trace_opts) */
+	uint32_t flags;            /* RTK_TRACE_* */
+	uint32_t image_width;      /* if both non-zero and width*height == n: rays are a   */
+	uint32_t image_height;     /* row-major image; lanes are mapped to 8x8 pixel tiles  */
+	uint32_t refill_min;       /* 0 = default; idle lanes needed before a wave refills  */
+	uint32_t blocks_per_cu;    /* 0 = default; persistent grid size                     */
+} rtk_trace_opts;
+#define RTK_TRACE_STATIC   1u   /* one fixed ray per lane, no persistent refill (A/B only) */
+
+/* Visit counters of the counting build (algorithmic-bytes model). */
+typedef struct rtk_trace_counters {
+	uint64_t rays;
+	uint64_t nodes;            /* 128 B node records fetched by rays  */
+	uint64_t leaves;
+	uint64_t triangles;        /* 48 B triangle records fetched       */
+	uint64_t hits;
+	uint64_t stack_spills;     /* pushes that went past the LDS stack */
+} rtk_trace_counters;
+
+/* -- scenes -- */
+rtk_dev_scene *rtk_dev_scene_upload(const rtk_scene *scene);
+rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc);
+void rtk_dev_scene_free(rtk_dev_scene *ds);
+int rtk_dev_scene_get_info(const rtk_dev_scene *ds, rtk_dev_scene_info *info);
+/* mesh_base[0..num_meshes] (prefix sums of per-mesh triangle counts) */
+int rtk_dev_scene_mesh_base(const rtk_dev_scene *ds, uint64_t *out, size_t capacity);
+size_t rtk_dev_scene_export_size(const rtk_dev_scene *ds);
+rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *ds, void *buffer, size_t size);
+
+/* -- batches; asynchronous on `stream` -- */
+int rtk_dev_trace_rays(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	rtk_hit_record *d_hits, const rtk_trace_opts *opts, void *stream);
+int rtk_dev_trace_rays_any(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	uint8_t *d_occluded, const rtk_trace_opts *opts, void *stream);
+int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n,
+	rtk_hit *d_hits, uint8_t *d_mask, void *stream);
+/* Same result as rtk_dev_trace_rays, plus visit counts. Synchronous; not for timing. */
+int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_trace_counters *out);
+
+/* -- host-pointer convenience (PCIe-inclusive, synchronous) --
+ * Closest hits of n rays against a scene blob. hits[i] is written where the ray hit
+ * (left untouched on a miss, like rtk_trace_ray); hit_mask[i] (optional) gets 0/1.
+ * Returns the number of hits, or (size_t)-1 on error. The device copy of the blob is
+ * cached per scene pointer until rtk_free_scene / rtk_amd_forget_scene. */
+size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask);
+void rtk_amd_forget_scene(const rtk_scene *scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_AMD_H */

@@ -87,7 +87,12 @@ def ref():
 
 
 def default_threads():
-    return max(1, min(os.cpu_count() or 1, lib().ora_max_threads()))
+    """Threads for the CPU legs: the cores this process may use, capped at a one-GPU box's share (16)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16, lib().ora_max_threads()))
 
 
 class Blob:

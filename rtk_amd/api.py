@@ -1,0 +1,318 @@
+"""Python host-side mirror of the rtk interface over librtk_amd.so (ctypes).
+
+Names follow the reference's API (reference rtk.h:119-130): build_scene / free_scene /
+trace_ray, plus the additive batch calls of include/rtk_amd.h. Everything goes through
+the C-ABI; there is no Python or CPU fallback -- if the HIP library is missing or no GPU
+is present the calls raise.
+
+torch is used only as plumbing: device buffers and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import (HIT_DTYPE, HIT_RECORD_DTYPE, RAY_DTYPE, MeshSet, SceneDesc, SceneHeader)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtk_amd.so")
+
+RTK_TRACE_STATIC = 1
+
+
+class RtkError(RuntimeError):
+    pass
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("num_triangles", C.c_uint64), ("num_meshes", C.c_uint64), ("num_nodes", C.c_uint64),
+                ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("total_device_bytes", C.c_uint64),
+                ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class TraceOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("image_width", C.c_uint32),
+                ("image_height", C.c_uint32), ("refill_min", C.c_uint32), ("blocks_per_cu", C.c_uint32)]
+
+
+class TraceCounters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("leaves", C.c_uint64),
+                ("triangles", C.c_uint64), ("hits", C.c_uint64), ("stack_spills", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+# every symbol include/rtk.h and include/rtk_amd.h declare
+RTK_H_SYMBOLS = ["rtk_start_build", "rtk_run_task", "rtk_get_build_size", "rtk_finish_build_to",
+                 "rtk_finish_build", "rtk_build_scene", "rtk_free_scene", "rtk_trace_ray", "rtk_trace_ray_filter"]
+RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_device",
+                     "rtk_dev_scene_upload", "rtk_dev_scene_build", "rtk_dev_scene_free", "rtk_dev_scene_get_info",
+                     "rtk_dev_scene_mesh_base", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
+                     "rtk_dev_trace_rays", "rtk_dev_trace_rays_any", "rtk_dev_expand_hits",
+                     "rtk_dev_trace_rays_counted", "rtk_trace_rays", "rtk_amd_forget_scene"]
+
+_lib = None
+
+
+def lib():
+    """Load librtk_amd.so (built by rtk_amd/csrc/Makefile). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtkError("%s not found: build it with `make -C rtk_amd/csrc` (or __graft_entry__.build()); "
+                       "there is no CPU fallback" % LIB_PATH)
+    # torch first: both link libamdhip64.so.7 and the process must end up with ONE HIP runtime
+    # (the one torch ships); loading ours first leaves torch.cuda unusable.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    L.rtk_amd_last_error.restype = C.c_char_p
+    L.rtk_amd_device_count.restype = C.c_int
+    L.rtk_amd_set_device.argtypes = [C.c_int]
+    L.rtk_dev_scene_upload.restype = C.c_void_p
+    L.rtk_dev_scene_upload.argtypes = [C.c_void_p]
+    L.rtk_dev_scene_build.restype = C.c_void_p
+    L.rtk_dev_scene_build.argtypes = [C.POINTER(SceneDesc)]
+    L.rtk_dev_scene_free.argtypes = [C.c_void_p]
+    L.rtk_dev_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+    L.rtk_dev_scene_mesh_base.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rtk_dev_scene_export_size.restype = C.c_size_t
+    L.rtk_dev_scene_export_size.argtypes = [C.c_void_p]
+    L.rtk_dev_scene_export.restype = C.c_void_p
+    L.rtk_dev_scene_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rtk_dev_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts), C.c_void_p]
+    L.rtk_dev_trace_rays_any.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts), C.c_void_p]
+    L.rtk_dev_expand_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtk_dev_trace_rays_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts),
+                                             C.POINTER(TraceCounters)]
+    L.rtk_trace_rays.restype = C.c_size_t
+    L.rtk_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.rtk_amd_forget_scene.argtypes = [C.c_void_p]
+    L.rtk_build_scene.restype = C.c_void_p
+    L.rtk_build_scene.argtypes = [C.POINTER(SceneDesc)]
+    L.rtk_free_scene.argtypes = [C.c_void_p]
+    L.rtk_trace_ray.restype = C.c_bool
+    L.rtk_trace_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtk_start_build.restype = C.c_void_p
+    L.rtk_start_build.argtypes = [C.POINTER(SceneDesc), C.c_void_p]
+    L.rtk_run_task.restype = C.c_size_t
+    L.rtk_run_task.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rtk_get_build_size.restype = C.c_size_t
+    L.rtk_get_build_size.argtypes = [C.c_void_p]
+    L.rtk_finish_build_to.restype = C.c_void_p
+    L.rtk_finish_build_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rtk_finish_build.restype = C.c_void_p
+    L.rtk_finish_build.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().rtk_amd_last_error().decode("utf-8", "replace")
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RtkError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RtkError("no GPU visible to torch: the rtk_amd trace path has no CPU fallback")
+    return torch
+
+
+def _stream_ptr():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def to_device(a):
+    """numpy structured/plain array -> uint8 cuda tensor holding the same bytes."""
+    torch = _torch()
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
+
+
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0):
+    o = TraceOpts()
+    o.struct_size = C.sizeof(TraceOpts)
+    o.flags = RTK_TRACE_STATIC if static else 0
+    if image:
+        o.image_width, o.image_height = int(image[0]), int(image[1])
+    o.refill_min = refill_min
+    o.blocks_per_cu = blocks_per_cu
+    return o
+
+
+class DeviceScene:
+    """A device-resident scene (rtk_dev_scene*)."""
+
+    def __init__(self, handle, keepalive=None):
+        if not handle:
+            raise RtkError("scene creation failed: " + last_error())
+        self.handle = C.c_void_p(handle)
+        self._keep = keepalive
+
+    @classmethod
+    def upload(cls, blob):
+        """blob: bytes-like / numpy uint8 / object with .ptr -- a scene blob in rtk format."""
+        _torch()
+        if hasattr(blob, "ptr"):
+            return cls(lib().rtk_dev_scene_upload(C.c_void_p(blob.ptr)), blob)
+        arr = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        arr = np.ascontiguousarray(arr)
+        return cls(lib().rtk_dev_scene_upload(C.c_void_p(arr.ctypes.data)), arr)
+
+    @classmethod
+    def build(cls, meshes):
+        """Device LBVH build from mesh dicts (see rtk_amd.types.MeshSet)."""
+        _torch()
+        ms = meshes if isinstance(meshes, MeshSet) else MeshSet(meshes)
+        return cls(lib().rtk_dev_scene_build(C.byref(ms.desc)), ms)
+
+    def free(self):
+        if self.handle:
+            lib().rtk_dev_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def info(self):
+        i = SceneInfo()
+        _check(lib().rtk_dev_scene_get_info(self.handle, C.byref(i)), "rtk_dev_scene_get_info")
+        return i.as_dict()
+
+    def mesh_base(self):
+        n = self.info()["num_meshes"] + 1
+        out = np.zeros(n, np.uint64)
+        rc = lib().rtk_dev_scene_mesh_base(self.handle, out.ctypes.data, n)
+        if rc < 0:
+            raise RtkError(last_error())
+        return out
+
+    def export_blob(self):
+        size = lib().rtk_dev_scene_export_size(self.handle)
+        if size == 0:
+            raise RtkError("rtk_dev_scene_export_size: " + last_error())
+        raw = np.zeros(size + 128, np.uint8)
+        off = (-raw.ctypes.data) % 128
+        buf = raw[off:off + size]
+        if not lib().rtk_dev_scene_export(self.handle, buf.ctypes.data, size):
+            raise RtkError("rtk_dev_scene_export: " + last_error())
+        return buf
+
+    # -- device-pointer batch calls (tensors are uint8 cuda tensors) --
+
+    def trace_device(self, d_rays, n, d_records=None, opts=None):
+        torch = _torch()
+        if d_records is None:
+            d_records = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+        _check(lib().rtk_dev_trace_rays(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_records.data_ptr()),
+                                        C.byref(opts) if opts is not None else None, _stream_ptr()), "rtk_dev_trace_rays")
+        return d_records
+
+    def trace_any_device(self, d_rays, n, d_occluded=None, opts=None):
+        torch = _torch()
+        if d_occluded is None:
+            d_occluded = torch.empty(n, dtype=torch.uint8, device="cuda")
+        _check(lib().rtk_dev_trace_rays_any(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_occluded.data_ptr()),
+                                            C.byref(opts) if opts is not None else None, _stream_ptr()), "rtk_dev_trace_rays_any")
+        return d_occluded
+
+    def expand_device(self, d_records, n):
+        torch = _torch()
+        d_hits = torch.empty(n * 68, dtype=torch.uint8, device="cuda")
+        d_mask = torch.empty(n, dtype=torch.uint8, device="cuda")
+        _check(lib().rtk_dev_expand_hits(self.handle, C.c_void_p(d_records.data_ptr()), n, C.c_void_p(d_hits.data_ptr()),
+                                         C.c_void_p(d_mask.data_ptr()), _stream_ptr()), "rtk_dev_expand_hits")
+        return d_hits, d_mask
+
+    # -- numpy conveniences used by the tests --
+
+    def trace(self, rays, opts=None, full=True):
+        """rays: numpy RAY_DTYPE. Returns (hits HIT_DTYPE, mask bool, records HIT_RECORD_DTYPE)."""
+        torch = _torch()
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype == RAY_DTYPE
+        n = rays.shape[0]
+        d_rays = to_device(rays)
+        d_rec = self.trace_device(d_rays, n, opts=opts)
+        rec = d_rec.cpu().numpy().view(HIT_RECORD_DTYPE)
+        if not full:
+            torch.cuda.synchronize()
+            return rec
+        d_hits, d_mask = self.expand_device(d_rec, n)
+        hits = d_hits.cpu().numpy().view(HIT_DTYPE)
+        mask = d_mask.cpu().numpy().astype(bool)
+        return hits, mask, rec
+
+    def trace_any(self, rays, opts=None):
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        d_rays = to_device(rays)
+        return self.trace_any_device(d_rays, n, opts=opts).cpu().numpy().astype(bool)
+
+    def trace_counted(self, rays, opts=None):
+        torch = _torch()
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        d_rays = to_device(rays)
+        d_rec = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+        ctr = TraceCounters()
+        torch.cuda.synchronize()
+        _check(lib().rtk_dev_trace_rays_counted(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_rec.data_ptr()),
+                                                C.byref(opts) if opts is not None else None, C.byref(ctr)),
+               "rtk_dev_trace_rays_counted")
+        return d_rec.cpu().numpy().view(HIT_RECORD_DTYPE), ctr.as_dict()
+
+
+# -- the reference's own entry points, host pointers (reference rtk.h:126-130) --
+
+def build_scene(meshes):
+    """rtk_build_scene: returns (scene pointer, MeshSet keepalive). Release with free_scene."""
+    _torch()
+    ms = meshes if isinstance(meshes, MeshSet) else MeshSet(meshes)
+    p = lib().rtk_build_scene(C.byref(ms.desc))
+    if not p:
+        raise RtkError("rtk_build_scene failed: " + last_error())
+    return p, ms
+
+
+def free_scene(scene_ptr):
+    lib().rtk_free_scene(C.c_void_p(scene_ptr))
+
+
+def scene_bytes(scene_ptr):
+    hdr = SceneHeader.from_address(scene_ptr)
+    return np.ctypeslib.as_array((C.c_uint8 * hdr.size_in_bytes).from_address(scene_ptr)).copy()
+
+
+def trace_ray(scene_ptr, ray):
+    """rtk_trace_ray: one ray (RAY_DTYPE scalar). Returns HIT_DTYPE record or None."""
+    _torch()
+    r = np.ascontiguousarray(ray).reshape(1)
+    h = np.zeros(1, HIT_DTYPE)
+    ok = lib().rtk_trace_ray(C.c_void_p(scene_ptr), r.ctypes.data, h.ctypes.data)
+    return h[0] if ok else None
+
+
+def trace_rays(scene_ptr, rays):
+    """rtk_trace_rays: host arrays in, host arrays out (PCIe inclusive)."""
+    _torch()
+    rays = np.ascontiguousarray(rays)
+    n = rays.shape[0]
+    hits = np.zeros(n, HIT_DTYPE)
+    mask = np.zeros(n, np.uint8)
+    r = lib().rtk_trace_rays(C.c_void_p(scene_ptr), rays.ctypes.data, n, hits.ctypes.data, mask.ctypes.data)
+    if r == C.c_size_t(-1).value:
+        raise RtkError("rtk_trace_rays failed: " + last_error())
+    return hits, mask.astype(bool)

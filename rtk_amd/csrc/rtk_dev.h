@@ -1,0 +1,97 @@
+// rtk_dev.h -- internal: device-side BVH layout and the host-side scene object.
+//
+// Data layout in HBM (DESIGN.md "Device layout"):
+//   DevNode  128 B = one L2 cache line: the reference's 4-wide SoA box block verbatim
+//            (rtk.c:69-74: bounds_x/y/z[min|max][slot]) followed by four 32-bit child
+//            references instead of four 64-bit byte offsets.
+//   DevTri   48 B = three float4: the three vertex positions pre-gathered (the reference
+//            chases leaf -> u8 index -> 16 B vertex, rtk.c:215-228), with the global
+//            primitive id and the end-of-leaf flag riding in the w lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "rtk.h"
+#include "rtk_amd.h"
+
+#define RTK_REF_NONE 0xffffffffu  // empty child slot / "no node"
+#define RTK_REF_LEAF 0x80000000u  // leaf: low 31 bits = first triangle slot
+#define RTK_TRI_LAST 1u           // DevTri.flags: last triangle of its leaf
+
+struct DevNode {
+	float bx[2][4];
+	float by[2][4];
+	float bz[2][4];
+	uint32_t child[4];
+	uint32_t pad[4];
+};
+static_assert(sizeof(DevNode) == 128, "node must be one 128 B line");
+
+struct DevTri {
+	float v0[3]; uint32_t prim;   // global primitive id
+	float v1[3]; uint32_t flags;  // RTK_TRI_LAST
+	float v2[3]; uint32_t spare;  // first record of a leaf: number of triangles in the leaf
+};
+static_assert(sizeof(DevTri) == 48, "triangle record is 48 B");
+
+// Everything a kernel needs to know about a scene (passed by value).
+struct DevSceneView {
+	const DevNode *nodes;
+	const DevTri *tris;
+	const uint32_t *vertex_index;  // [3*slot+k] original vertex index (rtk_vertex.index)
+	const uint32_t *prim_slot;     // [prim] -> triangle slot
+	const uint32_t *slot_mesh;     // [slot] -> mesh_index
+	const uint32_t *slot_tri;      // [slot] -> triangle_index (per mesh)
+	uint32_t num_nodes;
+	uint32_t num_tris;
+	uint32_t num_prims;
+};
+
+struct rtk_dev_scene {
+	int device = 0;
+	DevSceneView view = {};
+	// host copies kept for export / info
+	std::vector<uint64_t> mesh_base;  // num_meshes + 1
+	uint32_t max_depth = 0;
+	uint32_t stack_entries = 0;
+	uint64_t total_bytes = 0;
+	// owned device allocations
+	std::vector<void *> allocs;
+	// per-scene scratch for launches (lazily sized)
+	unsigned long long *d_counter = nullptr;   // ray pool head + visit counters (8 x u64)
+	uint2 *d_spill = nullptr;
+	size_t spill_entries_per_lane = 0;
+	size_t spill_lanes = 0;
+	int num_cus = 0;
+};
+
+// -- error plumbing (rtk_capi.hip) --
+void rtk_set_error(const char *fmt, ...);
+#define RTK_HIP_CHECK(expr, ret)                                                         \
+	do {                                                                                 \
+		hipError_t e_ = (expr);                                                          \
+		if (e_ != hipSuccess) {                                                          \
+			rtk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return ret;                                                                  \
+		}                                                                                \
+	} while (0)
+
+// -- upload (rtk_upload.hip) --
+struct HostBvh {
+	std::vector<DevNode> nodes;
+	std::vector<DevTri> tris;
+	std::vector<uint32_t> vertex_index;
+	std::vector<uint32_t> slot_mesh, slot_tri;
+	std::vector<uint64_t> mesh_base;
+	uint32_t max_depth = 0;
+};
+int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out);
+rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
+
+// -- trace launches (rtk_trace.hip) --
+int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
+	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted);
+int rtk_launch_expand(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,
+	uint8_t *d_mask, hipStream_t stream);

@@ -1,0 +1,474 @@
+// rtk_trace.hip -- BVH4 traversal + watertight triangle test for gfx950 (MI355X).
+//
+// What it computes is the reference's rtk_trace_ray (rtk.c:543-577) for a whole batch:
+//   ray setup        rtk.c:550-566   -> ray_setup()
+//   4-wide slab test rtk.c:457-472   -> node_step()
+//   triangle test    rtk.c:284-364   -> tri_test()   (per triangle, not per group of 4)
+//   closest update   rtk.c:366-386   -> canonical tie rule, DESIGN.md "Ties"
+// How it runs is CDNA4-specific: one ray per lane of a 64-wide wave, persistent waves
+// that pull ray chunks from a global counter and re-fill idle lanes by ballot rank, the
+// per-lane traversal stack in LDS ([entry][lane] so that a wave's push/pop is one
+// conflict-free ds_write_b64/ds_read_b64), 128 B nodes = one cache line per visit.
+//
+// FLOATING POINT: this file must be compiled with -ffp-contract=off. The float operation
+// order in tri_test() is normative (sign of u,v,w decides hit/miss); see SURVEY.md
+// section 0. Divisions are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+#include "rtk_dev.h"
+
+#include <math.h>
+#include <stdio.h>
+
+#define LDS_STACK 16           // entries per lane held in LDS
+#define WAVES_PER_BLOCK 4
+#define BLOCK_THREADS (64 * WAVES_PER_BLOCK)
+#define RAY_CHUNK 64           // rays taken from the global pool per atomic
+
+struct TraceParams {
+	DevSceneView sc;
+	const rtk_ray *rays;
+	rtk_hit_record *hits;
+	uint8_t *occluded;
+	unsigned long long *counter;   // [0] pool head, [1..6] visit counters
+	uint2 *spill;
+	unsigned long long n;
+	uint32_t spill_stride;         // lanes in the launch
+	uint32_t spill_cap;            // entries per lane in spill
+	uint32_t image_w, image_h;     // 0 = no tiling
+	uint32_t refill_min;
+	uint32_t dynamic;
+};
+
+// _mm_min_ps/_mm_max_ps semantics (second operand when the compare is false, NaN included)
+__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
+
+__device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
+
+__device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb)
+{
+	const bool s = kb < ka;
+	const float k0 = s ? kb : ka, k1 = s ? ka : kb;
+	const uint32_t r0 = s ? rb : ra, r1 = s ? ra : rb;
+	ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
+// Row-major image -> 8x8 pixel tiles, so that the 64 lanes of a wave share BVH nodes.
+__device__ __forceinline__ unsigned long long map_index(unsigned long long i, uint32_t w, uint32_t h)
+{
+	if (w == 0) return i;
+	const unsigned long long tile = i >> 6;
+	const uint32_t in = (uint32_t)i & 63u;
+	const uint32_t tiles_per_row = w >> 3;
+	const unsigned long long ty = tile / tiles_per_row;
+	const uint32_t tx = (uint32_t)(tile - ty * tiles_per_row);
+	const unsigned long long x = (unsigned long long)tx * 8u + (in & 7u);
+	const unsigned long long y = ty * 8u + (in >> 3);
+	return y * w + x;
+}
+
+template <int MODE /*0 closest, 1 any*/, bool COUNT>
+__global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
+{
+	__shared__ uint2 s_stack[WAVES_PER_BLOCK][LDS_STACK][64];
+
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	uint2 (*stk)[64] = s_stack[wave];
+	const uint32_t glane = blockIdx.x * BLOCK_THREADS + threadIdx.x;
+	const char *const nodes = reinterpret_cast<const char *>(p.sc.nodes);
+	const char *const tris = reinterpret_cast<const char *>(p.sc.tris);
+
+	// wave-uniform ray range owned by this wave
+	unsigned long long w_next, w_end;
+	bool pool_empty;
+	if (p.dynamic) {
+		w_next = w_end = 0;
+		pool_empty = false;
+	} else {
+		w_next = ((unsigned long long)blockIdx.x * WAVES_PER_BLOCK + wave) * 64ull;
+		w_end = w_next + 64ull < p.n ? w_next + 64ull : p.n;
+		if (w_next > p.n) w_next = p.n;
+		pool_empty = true;
+	}
+
+	// per-lane ray state
+	bool active = false;
+	unsigned long long ray_index = 0;
+	float ox = 0, oy = 0, oz = 0, rdx = 0, rdy = 0, rdz = 0, tmin_ray = 0, tmax_ray = 0;
+	float sox = 0, soy = 0, soz = 0, shx = 0, shy = 0, shz = 0;
+	bool kz0 = false, kz1 = false;
+	uint32_t onx = 0, ofx = 0, ony = 0, ofy = 0, onz = 0, ofz = 0;
+	float best_t = 0, best_u = 0, best_v = 0;
+	uint32_t best_prim = RTK_PRIM_NONE;
+	uint32_t top = RTK_REF_NONE;
+	uint32_t sp = 0;
+	uint32_t c_nodes = 0, c_leaves = 0, c_tris = 0, c_spills = 0;
+
+	for (;;) {
+		// ---------------------------------------------------------------- refill
+		const unsigned long long idle = __ballot(!active);
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if (n_idle == 64u || (n_idle >= p.refill_min && !(pool_empty && w_next >= w_end))) {
+			if (w_next >= w_end && !pool_empty) {
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(p.counter, (unsigned long long)RAY_CHUNK);
+				// all 64 lanes are converged here; lane 0's value becomes wave-uniform (SGPRs)
+				base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+					(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+				if (base >= p.n) {
+					pool_empty = true;
+				} else {
+					w_next = base;
+					w_end = base + RAY_CHUNK < p.n ? base + RAY_CHUNK : p.n;
+				}
+			}
+			const unsigned long long avail = w_end - w_next;
+			if (avail) {
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+					__builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+				const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
+				if (!active && rank < take) {
+					ray_index = map_index(w_next + rank, p.image_w, p.image_h);
+					const float4 r0 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index));
+					const float4 r1 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
+					ox = r0.x; oy = r0.y; oz = r0.z;
+					const float dx = r0.w, dy = r1.x, dz = r1.y;
+					tmin_ray = r1.z; tmax_ray = r1.w;
+					// rtk.c:550-566
+					const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+					const float m = sse_max(sse_max(ax, ay), az);
+					kz0 = ax == m;
+					kz1 = !kz0 && ay == m;
+					// (kx,ky,kz): kz==2 -> (x,y,z); kz==0 -> (y,z,x); kz==1 -> (z,x,y)
+					const float dkx = kz0 ? dy : (kz1 ? dz : dx);
+					const float dky = kz0 ? dz : (kz1 ? dx : dy);
+					const float dkz = kz0 ? dx : (kz1 ? dy : dz);
+					shx = -dkx / dkz;
+					shy = -dky / dkz;
+					shz = 1.0f / dkz;
+					sox = kz0 ? oy : (kz1 ? oz : ox);
+					soy = kz0 ? oz : (kz1 ? ox : oy);
+					soz = kz0 ? ox : (kz1 ? oy : oz);
+					// rtk.c:410: true divides
+					rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
+					// near/far plane offsets inside the node by direction sign BIT (rtk.c:152-154, 458-463)
+					const uint32_t sx = __float_as_uint(dx) >> 31, sy = __float_as_uint(dy) >> 31, sz = __float_as_uint(dz) >> 31;
+					onx = sx * 16u;        ofx = 16u - onx;
+					ony = 32u + sy * 16u;  ofy = 80u - ony;
+					onz = 64u + sz * 16u;  ofz = 144u - onz;
+					best_t = tmax_ray; best_u = 0.0f; best_v = 0.0f; best_prim = RTK_PRIM_NONE;
+					top = 0u;  // root node
+					sp = 0u;
+					active = true;
+				}
+				w_next += take;
+			}
+			if (__ballot(active) == 0ull) {
+				if (pool_empty && w_next >= w_end) break;
+				continue;
+			}
+		}
+
+		// ---------------------------------------------------------------- inner nodes
+		while (active && (int32_t)top >= 0) {
+			const char *nb = nodes + (size_t)top * 128u;
+			const float4 nx = ld_f4(nb + onx), fx = ld_f4(nb + ofx);
+			const float4 ny = ld_f4(nb + ony), fy = ld_f4(nb + ofy);
+			const float4 nz = ld_f4(nb + onz), fz = ld_f4(nb + ofz);
+			const uint4 ch = ld_u4(nb + 96);
+			if (COUNT) c_nodes++;
+			const float nxa[4] = { nx.x, nx.y, nx.z, nx.w }, fxa[4] = { fx.x, fx.y, fx.z, fx.w };
+			const float nya[4] = { ny.x, ny.y, ny.z, ny.w }, fya[4] = { fy.x, fy.y, fy.z, fy.w };
+			const float nza[4] = { nz.x, nz.y, nz.z, nz.w }, fza[4] = { fz.x, fz.y, fz.z, fz.w };
+			uint32_t ref[4] = { ch.x, ch.y, ch.z, ch.w };
+			float key[4];
+			uint32_t nhit = 0;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				// rtk.c:458-465: (bound - origin) * rcp_dir, then the folded interval test
+				const float ax = (nxa[i] - ox) * rdx, bx = (fxa[i] - ox) * rdx;
+				const float ay = (nya[i] - oy) * rdy, by = (fya[i] - oy) * rdy;
+				const float az = (nza[i] - oz) * rdz, bz = (fza[i] - oz) * rdz;
+				const float tn = sse_max(sse_max(ax, ay), sse_max(az, tmin_ray));
+				const float tf = sse_min(sse_min(bx, by), sse_min(bz, best_t));
+				const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
+				key[i] = h ? tn : __builtin_inff();
+				nhit += h ? 1u : 0u;
+			}
+			// nearest first (rtk.c:496-517 orders by entry distance)
+			cswap(key[0], ref[0], key[1], ref[1]);
+			cswap(key[2], ref[2], key[3], ref[3]);
+			cswap(key[0], ref[0], key[2], ref[2]);
+			cswap(key[1], ref[1], key[3], ref[3]);
+			cswap(key[1], ref[1], key[2], ref[2]);
+			if (nhit == 0u) {
+				// pop, skipping entries that start behind the current hit (rtk.c:432)
+				top = RTK_REF_NONE;
+				while (sp > 0u) {
+					--sp;
+					const uint2 e = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane];
+					if (__uint_as_float(e.x) > best_t) continue;
+					top = e.y;
+					break;
+				}
+			} else {
+				top = ref[0];
+#pragma unroll
+				for (int i = 3; i >= 1; i--) {
+					if (nhit > (uint32_t)i) {
+						const uint2 e = make_uint2(__float_as_uint(key[i]), ref[i]);
+						if (sp < LDS_STACK) stk[sp][lane] = e;
+						else if (sp - LDS_STACK < p.spill_cap) { p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane] = e; if (COUNT) c_spills++; }
+						sp++;
+					}
+				}
+			}
+		}
+
+		// ---------------------------------------------------------------- leaf
+		// Triangles are taken one at a time but in the reference's groups of four
+		// (rtk.c:212): if any slot of a group -- padding slots of a partial last group
+		// included -- has an edge function that is exactly zero, ALL slots of the group
+		// use the double-precision edge functions (rtk.c:302-336). A partial group is
+		// known up front; a zero inside a full group is rare, so the group is simply
+		// redone from a snapshot of the best hit. This keeps t/u/v bit-identical to
+		// rtk.c traversing the same leaves.
+		if (active && top != RTK_REF_NONE) {
+			const uint32_t slot0 = top & 0x7fffffffu;
+			if (COUNT) c_leaves++;
+			uint32_t i = 0, n = 1;
+			bool force = false, redo = false;
+			float sn_t = best_t, sn_u = best_u, sn_v = best_v;
+			uint32_t sn_prim = best_prim;
+			while (i < n) {
+				const char *tb = tris + (size_t)(slot0 + i) * 48u;
+				const float4 A = ld_f4(tb), B = ld_f4(tb + 16), C = ld_f4(tb + 32);
+				if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
+				if ((i & 3u) == 0u) {
+					if (redo) { force = true; redo = false; }
+					else {
+						if (MODE == 1 && best_prim != RTK_PRIM_NONE) break;   // any-hit: a whole group accepted something
+						force = (n - i) < 4u;
+						sn_t = best_t; sn_u = best_u; sn_v = best_v; sn_prim = best_prim;
+					}
+				}
+				if (COUNT) c_tris++;
+				// permute to (kx,ky,kz) and move the origin (rtk.c:232-280)
+				const float v0x = (kz0 ? A.y : (kz1 ? A.z : A.x)) - sox;
+				const float v0y = (kz0 ? A.z : (kz1 ? A.x : A.y)) - soy;
+				const float v0z = (kz0 ? A.x : (kz1 ? A.y : A.z)) - soz;
+				const float v1x = (kz0 ? B.y : (kz1 ? B.z : B.x)) - sox;
+				const float v1y = (kz0 ? B.z : (kz1 ? B.x : B.y)) - soy;
+				const float v1z = (kz0 ? B.x : (kz1 ? B.y : B.z)) - soz;
+				const float v2x = (kz0 ? C.y : (kz1 ? C.z : C.x)) - sox;
+				const float v2y = (kz0 ? C.z : (kz1 ? C.x : C.y)) - soy;
+				const float v2z = (kz0 ? C.x : (kz1 ? C.y : C.z)) - soz;
+				// shear (rtk.c:284-292)
+				const float x0 = v0x + shx * v0z, y0 = v0y + shy * v0z, z0 = shz * v0z;
+				const float x1 = v1x + shx * v1z, y1 = v1y + shy * v1z, z1 = shz * v1z;
+				const float x2 = v2x + shx * v2z, y2 = v2y + shy * v2z, z2 = shz * v2z;
+				// edge functions (rtk.c:298-300)
+				float u, v, w;
+				if (!force) {
+					u = x1 * y2 - y1 * x2;
+					v = x2 * y0 - y2 * x0;
+					w = x0 * y1 - y0 * x1;
+					if (u == 0.0f || v == 0.0f || w == 0.0f) {
+						// rtk.c:306: the whole group switches to double precision
+						best_t = sn_t; best_u = sn_u; best_v = sn_v; best_prim = sn_prim;
+						redo = true;
+						i &= ~3u;
+						continue;
+					}
+				} else {
+					const double xd0 = x0, yd0 = y0, xd1 = x1, yd1 = y1, xd2 = x2, yd2 = y2;
+					u = (float)(xd1 * yd2 - yd1 * xd2);
+					v = (float)(xd2 * yd0 - yd2 * xd0);
+					w = (float)(xd0 * yd1 - yd0 * xd1);
+				}
+				// rtk.c:340-342
+				const bool neg = sse_min(sse_min(u, v), w) < 0.0f;
+				const bool pos = sse_max(sse_max(u, v), w) > 0.0f;
+				// rtk.c:346-353
+				const float det = (u + v) + w;
+				const float rcp = 1.0f / det;
+				float zz = u * z0;
+				zz = zz + v * z1;
+				zz = zz + w * z2;
+				const float t = zz * rcp;
+				const uint32_t prim = __float_as_uint(A.w);
+				const bool in_range = !(neg && pos) && t > tmin_ray && t < tmax_ray;   // rtk.c:354
+				if (MODE == 1) {
+					if (in_range && best_prim == RTK_PRIM_NONE) { best_prim = prim; best_t = t; }
+				} else {
+					// rtk.c:371 with the canonical tie rule: lowest primitive id among bit-equal t
+					if (in_range && (t < best_t || (t == best_t && prim < best_prim))) {
+						best_t = t; best_u = u * rcp; best_v = v * rcp; best_prim = prim;
+					}
+				}
+				i++;
+			}
+			if (MODE == 1 && best_prim != RTK_PRIM_NONE) {
+				top = RTK_REF_NONE;
+				sp = 0u;
+			} else {
+				top = RTK_REF_NONE;
+				while (sp > 0u) {
+					--sp;
+					const uint2 e = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane];
+					if (__uint_as_float(e.x) > best_t) continue;
+					top = e.y;
+					break;
+				}
+			}
+		}
+
+		// ---------------------------------------------------------------- retire
+		if (active && top == RTK_REF_NONE) {
+			if (MODE == 1) {
+				p.occluded[ray_index] = best_prim != RTK_PRIM_NONE ? 1 : 0;
+			} else {
+				rtk_hit_record r;
+				r.t = best_t; r.u = best_u; r.v = best_v; r.prim = best_prim;
+				*reinterpret_cast<float4 *>(p.hits + ray_index) =
+					make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));
+			}
+			if (COUNT) {
+				atomicAdd(p.counter + 1, 1ull);
+				atomicAdd(p.counter + 2, (unsigned long long)c_nodes);
+				atomicAdd(p.counter + 3, (unsigned long long)c_leaves);
+				atomicAdd(p.counter + 4, (unsigned long long)c_tris);
+				atomicAdd(p.counter + 5, best_prim != RTK_PRIM_NONE ? 1ull : 0ull);
+				atomicAdd(p.counter + 6, (unsigned long long)c_spills);
+				c_nodes = c_leaves = c_tris = c_spills = 0;
+			}
+			active = false;
+		}
+	}
+}
+
+// Full rtk_hit from a compact record (rtk.c:372-380 copy-out).
+__global__ void rtk_expand_kernel(DevSceneView sc, const rtk_hit_record *rec, unsigned long long n, rtk_hit *hits, uint8_t *mask)
+{
+	const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const rtk_hit_record r = rec[i];
+	const bool hit = r.prim != RTK_PRIM_NONE && r.prim < sc.num_prims;
+	if (mask) mask[i] = hit ? 1 : 0;
+	if (!hit || !hits) return;
+	const uint32_t slot = sc.prim_slot[r.prim];
+	const DevTri tr = sc.tris[slot];
+	rtk_hit h;
+	h.t = r.t; h.u = r.u; h.v = r.v;
+	h.vertex[0].position.x = tr.v0[0]; h.vertex[0].position.y = tr.v0[1]; h.vertex[0].position.z = tr.v0[2];
+	h.vertex[1].position.x = tr.v1[0]; h.vertex[1].position.y = tr.v1[1]; h.vertex[1].position.z = tr.v1[2];
+	h.vertex[2].position.x = tr.v2[0]; h.vertex[2].position.y = tr.v2[1]; h.vertex[2].position.z = tr.v2[2];
+	h.vertex[0].index = sc.vertex_index[3u * slot + 0u];
+	h.vertex[1].index = sc.vertex_index[3u * slot + 1u];
+	h.vertex[2].index = sc.vertex_index[3u * slot + 2u];
+	h.mesh_index = sc.slot_mesh[slot];
+	h.triangle_index = sc.slot_tri[slot];
+	hits[i] = h;
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+
+template <int MODE, bool COUNT>
+static int occupancy_blocks()
+{
+	int nb = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk_trace_kernel<MODE, COUNT>, BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
+	return nb;
+}
+
+int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
+	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted)
+{
+	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
+	if (!ds || (!d_rays && n) || ((any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
+	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
+
+	TraceParams p = {};
+	p.sc = ds->view;
+	p.rays = d_rays;
+	p.hits = d_hits;
+	p.occluded = d_occluded;
+	p.n = n;
+	p.dynamic = 1;
+	p.refill_min = 64;
+	uint32_t blocks_per_cu = 0;
+	if (opts && opts->struct_size >= 16) {
+		if (opts->flags & RTK_TRACE_STATIC) p.dynamic = 0;
+		if (opts->image_width && opts->image_height && (size_t)opts->image_width * opts->image_height == n &&
+			(opts->image_width % 8u) == 0 && (opts->image_height % 8u) == 0) {
+			p.image_w = opts->image_width;
+			p.image_h = opts->image_height;
+		}
+		if (opts->struct_size >= 24) {
+			if (opts->refill_min) p.refill_min = opts->refill_min > 64 ? 64 : opts->refill_min;
+			blocks_per_cu = opts->blocks_per_cu;
+		}
+	}
+
+	static int occ[2][2] = { { 0, 0 }, { 0, 0 } };
+	int &o = occ[any_hit ? 1 : 0][counted ? 1 : 0];
+	if (o == 0) {
+		o = any_hit ? (counted ? occupancy_blocks<1, true>() : occupancy_blocks<1, false>())
+		            : (counted ? occupancy_blocks<0, true>() : occupancy_blocks<0, false>());
+	}
+	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)o) blocks_per_cu = (uint32_t)o;
+
+	const size_t blocks_needed = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
+	size_t blocks = p.dynamic ? (size_t)ds->num_cus * blocks_per_cu : blocks_needed;
+	if (blocks > blocks_needed) blocks = blocks_needed;
+	if (blocks > 0x7fffffffu) { rtk_set_error("rtk_dev_trace: batch too large for one launch"); return RTK_AMD_ERR_BAD_ARG; }
+
+	// spill area for rays whose stack outgrows LDS
+	const size_t lanes = blocks * BLOCK_THREADS;
+	const size_t spill_cap = ds->stack_entries > LDS_STACK ? ds->stack_entries - LDS_STACK : 0;
+	if (spill_cap && (ds->spill_lanes < lanes || ds->spill_entries_per_lane < spill_cap)) {
+		if (ds->d_spill) (void)hipFree(ds->d_spill);
+		ds->d_spill = nullptr;
+		RTK_HIP_CHECK(hipMalloc(&ds->d_spill, lanes * spill_cap * sizeof(uint2)), RTK_AMD_ERR_OOM);
+		ds->spill_lanes = lanes;
+		ds->spill_entries_per_lane = spill_cap;
+	}
+	p.spill = ds->d_spill;
+	p.spill_stride = (uint32_t)(spill_cap ? ds->spill_lanes : 0);
+	p.spill_cap = (uint32_t)spill_cap;
+	p.counter = ds->d_counter;
+
+	RTK_HIP_CHECK(hipMemsetAsync(ds->d_counter, 0, 8 * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	const dim3 grid((unsigned)blocks), block(BLOCK_THREADS);
+	if (any_hit) {
+		if (counted) hipLaunchKernelGGL((rtk_trace_kernel<1, true>), grid, block, 0, stream, p);
+		else hipLaunchKernelGGL((rtk_trace_kernel<1, false>), grid, block, 0, stream, p);
+	} else {
+		if (counted) hipLaunchKernelGGL((rtk_trace_kernel<0, true>), grid, block, 0, stream, p);
+		else hipLaunchKernelGGL((rtk_trace_kernel<0, false>), grid, block, 0, stream, p);
+	}
+	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
+	if (counted) {
+		unsigned long long c[8];
+		RTK_HIP_CHECK(hipMemcpyAsync(c, ds->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
+		counted->rays = c[1]; counted->nodes = c[2]; counted->leaves = c[3];
+		counted->triangles = c[4]; counted->hits = c[5]; counted->stack_spills = c[6];
+	}
+	return RTK_AMD_OK;
+}
+
+int rtk_launch_expand(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,
+	uint8_t *d_mask, hipStream_t stream)
+{
+	if (!ds || (!d_records && n)) { rtk_set_error("rtk_dev_expand_hits: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
+	if (n == 0) return RTK_AMD_OK;
+	const size_t blocks = (n + 255) / 256;
+	hipLaunchKernelGGL(rtk_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ds->view, d_records,
+		(unsigned long long)n, d_hits, d_mask);
+	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
+	return RTK_AMD_OK;
+}
