@@ -1,16 +1,1136 @@
-// rtk_build.hip -- scene construction entry points (rtk.h:119-127). PLACEHOLDER until the
-// device LBVH builder lands: every entry point fails loudly.
+// rtk_build.hip -- scene construction on the GPU (gfx950): Morton-code LBVH, bottom-up
+// refit with a surface-area leaf/treelet decision, greedy collapse to 4-wide nodes.
+//
+// Stands in for the reference's CPU builder (rtk.c:1362-1622: triangle setup tasks,
+// binned-SAH node tasks, finalize, linearize). The reference's topology is not part of
+// the parity contract -- only the hits are -- so the construction is re-designed for the
+// GPU; what IS kept from the reference: triangle identity (mesh_index, per-mesh
+// triangle_index, rtk.c:1168-1169), index/position decoding rules (rtk.c:1028-1114),
+// <= 63 triangles per leaf (rtk.c:188), and the blob format on export.
+//
+// Stages (all device kernels; the host only sequences launches):
+//   1 ingest     decode indices + positions of every mesh into staged triangles
+//   2 bounds     centroid bounds (wave shuffle -> LDS -> one atomic per block)
+//   3 morton     63-bit Morton key per triangle
+//   4 sort       LSD radix sort, 8-bit digits, per-wave LDS histograms and counters
+//   5 emit       triangles gathered into Morton order = final 48 B leaf records
+//   6 karras     binary radix tree over the sorted keys (Karras 2012)
+//   7 refit      bottom-up AABBs + SAH leaf decision (agent-scope acq_rel arrival counters)
+//   8 collapse   breadth-first, level by level: binary tree -> 128 B 4-wide nodes
 #include "rtk_dev.h"
 
+#include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
-extern "C" rtk_build *rtk_start_build(const rtk_scene_desc *, rtk_task *) { rtk_set_error("rtk_start_build: device builder not built yet"); return nullptr; }
-extern "C" size_t rtk_run_task(const rtk_task *, rtk_task *, size_t) { return 0; }
-extern "C" size_t rtk_get_build_size(const rtk_build *) { return 0; }
-extern "C" rtk_scene *rtk_finish_build_to(rtk_build *, void *, size_t) { return nullptr; }
-extern "C" rtk_scene *rtk_finish_build(rtk_build *) { return nullptr; }
-extern "C" rtk_scene *rtk_build_scene(const rtk_scene_desc *) { rtk_set_error("rtk_build_scene: device builder not built yet"); return nullptr; }
-extern "C" void rtk_free_scene(rtk_scene *scene) { if (scene) { rtk_amd_forget_scene(scene); free(scene); } }
-extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *) { rtk_set_error("rtk_dev_scene_build: device builder not built yet"); return nullptr; }
-extern "C" size_t rtk_dev_scene_export_size(const rtk_dev_scene *) { return 0; }
-extern "C" rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *, void *, size_t) { rtk_set_error("rtk_dev_scene_export: not built yet"); return nullptr; }
+#include <algorithm>
+#include <unordered_map>
+
+void rtk_cache_adopt(const rtk_scene *scene, rtk_dev_scene *ds);
+
+namespace {
+
+#define SORT_WAVE_ITEMS 1024u     // keys handled by one wave per pass (16 chunks of 64)
+#define SORT_BLOCK 256
+
+struct BinNode {                  // 32 B, written by refit
+	float mn[3];
+	uint32_t cnt_flag;            // bits 0..30 triangles below, bit 31 = collapses to ONE leaf
+	float mx[3];
+	float cost;
+};
+static_assert(sizeof(BinNode) == 32, "BinNode");
+
+struct BuildParams {
+	float cost_tri;               // per triangle tested
+	float cost_node;              // per binary inner node
+	uint32_t max_leaf;
+};
+
+// ---------------------------------------------------------------------------------- 1 ingest
+
+// IDX: 0 implicit (3i,3i+1,3i+2), 1 u16, 2 u32 (rtk.c:1028-1070). F64: positions are doubles (rtk.c:1098, B20).
+// Compile-time variants on purpose: the run-time if/else-if/else form of this kernel was
+// miscompiled by hipcc 7.2 for gfx950 (the u32 arm lost the initialisation of the output index).
+template <int IDX, bool F64>
+__global__ void k_ingest(const char *pos, unsigned long long pos_stride, const char *idx,
+	unsigned long long idx_stride, uint32_t ntris, uint32_t base, float *in_pos, uint32_t *in_vidx)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= ntris) return;
+	uint32_t v0, v1, v2;
+	if (IDX == 0) {
+		v0 = 3u * i; v1 = 3u * i + 1u; v2 = 3u * i + 2u;
+	} else if (IDX == 1) {
+		const uint16_t *p = reinterpret_cast<const uint16_t *>(idx + (size_t)i * idx_stride);
+		v0 = p[0]; v1 = p[1]; v2 = p[2];
+	} else {
+		const uint32_t *p = reinterpret_cast<const uint32_t *>(idx + (size_t)i * idx_stride);
+		v0 = p[0]; v1 = p[1]; v2 = p[2];
+	}
+	const uint32_t vi[3] = { v0, v1, v2 };
+	const size_t g = (size_t)base + (size_t)i;
+	float *out = in_pos + 9 * g;
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		float x, y, z;
+		if (F64) {
+			const double *p = reinterpret_cast<const double *>(pos + (size_t)vi[c] * pos_stride);
+			x = (float)p[0]; y = (float)p[1]; z = (float)p[2];
+		} else {
+			const float *p = reinterpret_cast<const float *>(pos + (size_t)vi[c] * pos_stride);
+			x = p[0]; y = p[1]; z = p[2];
+		}
+		out[3 * c + 0] = x;
+		out[3 * c + 1] = y;
+		out[3 * c + 2] = z;
+		in_vidx[3 * g + c] = vi[c];
+	}
+}
+
+template <int IDX>
+void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
+	unsigned long long istride, uint32_t nt, uint32_t base, float *in_pos, uint32_t *in_vidx)
+{
+	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_pos, in_vidx);
+	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_pos, in_vidx);
+}
+
+// ---------------------------------------------------------------------------------- 2 bounds
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+	const uint32_t b = __float_as_uint(f);
+	return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u)
+{
+	return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// bounds[0..2] = min of centroid*2 (ordered uint), bounds[3..5] = max
+__global__ void k_bounds(const float *in_pos, uint32_t n, uint32_t *bounds)
+{
+	__shared__ float s_mn[3][SORT_BLOCK / 64], s_mx[3][SORT_BLOCK / 64];
+	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const float *p = in_pos + 9 * i;
+#pragma unroll
+		for (int a = 0; a < 3; a++) {
+			const float lo = fminf(fminf(p[a], p[3 + a]), p[6 + a]);
+			const float hi = fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
+			const float c2 = lo + hi;
+			mn[a] = fminf(mn[a], c2);
+			mx[a] = fmaxf(mx[a], c2);
+		}
+	}
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		for (int o = 32; o > 0; o >>= 1) {
+			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+		}
+		if ((threadIdx.x & 63u) == 0) { s_mn[a][threadIdx.x >> 6] = mn[a]; s_mx[a][threadIdx.x >> 6] = mx[a]; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		const int a = threadIdx.x;
+		float lo = s_mn[a][0], hi = s_mx[a][0];
+		for (int w = 1; w < SORT_BLOCK / 64; w++) { lo = fminf(lo, s_mn[a][w]); hi = fmaxf(hi, s_mx[a][w]); }
+		atomicMin(&bounds[a], f2ord(lo));
+		atomicMax(&bounds[3 + a], f2ord(hi));
+	}
+}
+
+// ---------------------------------------------------------------------------------- 3 morton
+
+__device__ __forceinline__ unsigned long long spread21(uint32_t v)
+{
+	unsigned long long x = v & 0x1fffffu;
+	x = (x | (x << 32)) & 0x1f00000000ffffull;
+	x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+	x = (x | (x << 8)) & 0x100f00f00f00f00full;
+	x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+	x = (x | (x << 2)) & 0x1249249249249249ull;
+	return x;
+}
+
+__global__ void k_morton(const float *in_pos, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float *p = in_pos + 9 * (size_t)i;
+	uint32_t q[3];
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		const float lo = ord2f(bounds[a]), hi = ord2f(bounds[3 + a]);
+		const float c2 = fminf(fminf(p[a], p[3 + a]), p[6 + a]) + fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
+		const float ext = hi - lo;
+		float t = ext > 0.0f ? (c2 - lo) / ext : 0.0f;
+		t = fminf(fmaxf(t, 0.0f), 1.0f);
+		uint32_t v = (uint32_t)(t * 2097152.0f);
+		q[a] = v > 2097151u ? 2097151u : v;
+	}
+	keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+	vals[i] = i;
+}
+
+// ---------------------------------------------------------------------------------- 4 radix sort
+// Unit of work = one wave = SORT_WAVE_ITEMS consecutive keys. hist is digit-major:
+// hist[digit * num_units + unit], so one exclusive scan over the whole array yields, for
+// every (digit, unit), the first output position of that unit's keys with that digit.
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort_hist(const unsigned long long *keys, uint32_t n, uint32_t shift,
+	uint32_t num_units, uint32_t *hist)
+{
+	__shared__ uint32_t s_h[SORT_BLOCK / 64][256];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t unit = blockIdx.x * (SORT_BLOCK / 64) + wave;
+	for (int j = 0; j < 4; j++) s_h[wave][lane + 64 * j] = 0;
+	__syncthreads();
+	if (unit < num_units) {
+		const size_t base = (size_t)unit * SORT_WAVE_ITEMS;
+		for (uint32_t c = 0; c < SORT_WAVE_ITEMS / 64u; c++) {
+			const size_t i = base + c * 64u + lane;
+			if (i < n) atomicAdd(&s_h[wave][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+		}
+	}
+	__syncthreads();
+	if (unit < num_units)
+		for (int j = 0; j < 4; j++) hist[(size_t)(lane + 64 * j) * num_units + unit] = s_h[wave][lane + 64 * j];
+}
+
+// exclusive scan of a uint32 array, three launches (block sums -> scan of sums -> add)
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 16             // per thread -> 4096 per block
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block(uint32_t *data, size_t n, uint32_t *block_sums)
+{
+	__shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+	const size_t base = (size_t)blockIdx.x * (SCAN_BLOCK * SCAN_ITEMS) + (size_t)threadIdx.x * SCAN_ITEMS;
+	uint32_t v[SCAN_ITEMS];
+	uint32_t sum = 0;
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? data[base + k] : 0u; sum += v[k]; }
+	// inclusive scan of `sum` across the wave
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t inc = sum;
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+	if (lane == 63u) s_wave[wave] = inc;
+	__syncthreads();
+	uint32_t wave_off = 0;
+	for (uint32_t w = 0; w < wave; w++) wave_off += s_wave[w];
+	uint32_t run = wave_off + inc - sum;
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) data[base + k] = run; run += v[k]; }
+	if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *sums, uint32_t n)
+{
+	// single block; n block sums, processed in strips of 1024 with a running carry
+	__shared__ uint32_t s_wave[16];
+	__shared__ uint32_t s_carry;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) s_carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < n; base += 1024u) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < n ? sums[i] : 0u;
+		uint32_t inc = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+		if (lane == 63u) s_wave[wave] = inc;
+		__syncthreads();
+		uint32_t off = s_carry;
+		for (uint32_t w = 0; w < wave; w++) off += s_wave[w];
+		if (i < n) sums[i] = off + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 1023u) s_carry = off + inc;
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t *data, size_t n, const uint32_t *block_sums)
+{
+	const uint32_t add = block_sums[blockIdx.x];
+	const size_t base = (size_t)blockIdx.x * (SCAN_BLOCK * SCAN_ITEMS) + (size_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+	for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) data[base + k] += add;
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long long *keys_in, const uint32_t *vals_in, uint32_t n,
+	uint32_t shift, uint32_t num_units, const uint32_t *hist, unsigned long long *keys_out, uint32_t *vals_out)
+{
+	__shared__ uint32_t s_pos[SORT_BLOCK / 64][256];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t unit = blockIdx.x * (SORT_BLOCK / 64) + wave;
+	if (unit >= num_units) return;          // whole wave leaves together; no block barrier below
+	for (int j = 0; j < 4; j++) s_pos[wave][lane + 64 * j] = hist[(size_t)(lane + 64 * j) * num_units + unit];
+	const size_t base = (size_t)unit * SORT_WAVE_ITEMS;
+	const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
+	for (uint32_t c = 0; c < SORT_WAVE_ITEMS / 64u; c++) {
+		const size_t i = base + c * 64u + lane;
+		const bool valid = i < n;
+		const unsigned long long key = valid ? keys_in[i] : 0ull;
+		const uint32_t val = valid ? vals_in[i] : 0u;
+		const uint32_t d = (uint32_t)(key >> shift) & 255u;
+		// lanes of this chunk holding the same digit (8 ballots)
+		unsigned long long same = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < 8; b++) {
+			const bool bit = (d >> b) & 1u;
+			const unsigned long long vote = __ballot(bit);
+			same &= bit ? vote : ~vote;
+		}
+		if (valid) {
+			const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
+			const uint32_t start = s_pos[wave][d];                 // all lanes read before any leader writes (wave program order)
+			const uint32_t dst = start + rank;
+			keys_out[dst] = key;
+			vals_out[dst] = val;
+			if (rank == 0u) s_pos[wave][d] = start + (uint32_t)__popcll(same);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------- 5 emit
+
+__global__ void k_emit_tris(const float *in_pos, const uint32_t *in_vidx, const uint32_t *vals, uint32_t n,
+	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris, uint32_t *vertex_index,
+	uint32_t *prim_slot, uint32_t *slot_mesh, uint32_t *slot_tri)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const uint32_t g = vals[s];
+	const float *p = in_pos + 9 * (size_t)g;
+	DevTri t;
+	t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2]; t.prim = g;
+	t.v1[0] = p[3]; t.v1[1] = p[4]; t.v1[2] = p[5]; t.flags = 0u;
+	t.v2[0] = p[6]; t.v2[1] = p[7]; t.v2[2] = p[8]; t.spare = 0u;
+	tris[s] = t;
+	vertex_index[3 * (size_t)s + 0] = in_vidx[3 * (size_t)g + 0];
+	vertex_index[3 * (size_t)s + 1] = in_vidx[3 * (size_t)g + 1];
+	vertex_index[3 * (size_t)s + 2] = in_vidx[3 * (size_t)g + 2];
+	prim_slot[g] = s;
+	// mesh of global primitive g: last m with mesh_base[m] <= g
+	uint32_t lo = 0, hi = num_meshes;
+	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
+	slot_mesh[s] = lo;
+	slot_tri[s] = g - (uint32_t)mesh_base[lo];
+}
+
+// ---------------------------------------------------------------------------------- 6 karras
+
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j)
+{
+	if (j < 0 || j >= n) return -1;
+	const unsigned long long a = keys[i], b = keys[j];
+	if (a == b) return 64 + __clz((unsigned)(i ^ j));
+	return __clzll((long long)(a ^ b));
+}
+
+// children: >= 0 inner node index, < 0 leaf ~index
+__global__ void k_karras(const unsigned long long *keys, int n, int *left, int *right, int *parent_inner, int *parent_leaf,
+	uint32_t *range_first, uint32_t *range_last)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1) return;
+	const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+	const int dmin = delta(keys, n, i, i - d);
+	int lmax = 2;
+	while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+	int l = 0;
+	for (int t = lmax >> 1; t >= 1; t >>= 1)
+		if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+	const int j = i + l * d;
+	const int dnode = delta(keys, n, i, j);
+	int s = 0;
+	int t = l;
+	do {
+		t = (t + 1) >> 1;
+		if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+	} while (t > 1);
+	const int gamma = i + s * d + (d < 0 ? -1 : 0);
+	const int lo = i < j ? i : j, hi = i < j ? j : i;
+	const int lc = lo == gamma ? ~gamma : gamma;
+	const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+	left[i] = lc;
+	right[i] = rc;
+	range_first[i] = (uint32_t)lo;
+	range_last[i] = (uint32_t)hi;
+	if (lc >= 0) parent_inner[lc] = i; else parent_leaf[~lc] = i;
+	if (rc >= 0) parent_inner[rc] = i; else parent_leaf[~rc] = i;
+	if (i == 0) parent_inner[0] = -1;
+}
+
+// ---------------------------------------------------------------------------------- 7 refit + SAH
+
+__device__ __forceinline__ float half_area(const float mn[3], const float mx[3])
+{
+	const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+	return x * y + y * z + z * x;
+}
+
+__device__ __forceinline__ void tri_box(const DevTri *tris, uint32_t s, float mn[3], float mx[3])
+{
+	const DevTri &t = tris[s];
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		mn[a] = fminf(fminf(t.v0[a], t.v1[a]), t.v2[a]);
+		mx[a] = fmaxf(fmaxf(t.v0[a], t.v1[a]), t.v2[a]);
+	}
+}
+
+// One thread per sorted triangle walks towards the root; the second thread to arrive at a
+// node (agent-scope acq_rel counter) owns it. The acq_rel arrival makes the first
+// arriver's BinNode visible to the second whichever CUs/XCDs they ran on.
+__global__ void k_refit(const DevTri *tris, int n, const int *left, const int *right, const int *parent_inner,
+	const int *parent_leaf, uint32_t *arrive, BinNode *bin, BuildParams bp)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int node = parent_leaf[i];
+	while (node >= 0) {
+		const uint32_t old = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (old == 0u) return;
+		float mn[3], mx[3], cost = 0.0f;
+		uint32_t cnt = 0;
+		for (int side = 0; side < 2; side++) {
+			const int c = side == 0 ? left[node] : right[node];
+			float cmn[3], cmx[3], ccost;
+			uint32_t ccnt;
+			if (c < 0) {
+				tri_box(tris, (uint32_t)~c, cmn, cmx);
+				ccnt = 1u;
+				ccost = bp.cost_tri * half_area(cmn, cmx);
+			} else {
+				const BinNode b = bin[c];
+				cmn[0] = b.mn[0]; cmn[1] = b.mn[1]; cmn[2] = b.mn[2];
+				cmx[0] = b.mx[0]; cmx[1] = b.mx[1]; cmx[2] = b.mx[2];
+				ccnt = b.cnt_flag & 0x7fffffffu;
+				ccost = b.cost;
+			}
+			if (side == 0) { for (int a = 0; a < 3; a++) { mn[a] = cmn[a]; mx[a] = cmx[a]; } }
+			else { for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], cmn[a]); mx[a] = fmaxf(mx[a], cmx[a]); } }
+			cnt += ccnt;
+			cost += ccost;
+		}
+		const float area = half_area(mn, mx);
+		const float split = bp.cost_node * area + cost;
+		const float leaf = cnt <= bp.max_leaf ? bp.cost_tri * (float)cnt * area : INFINITY;
+		BinNode out;
+		out.mn[0] = mn[0]; out.mn[1] = mn[1]; out.mn[2] = mn[2];
+		out.mx[0] = mx[0]; out.mx[1] = mx[1]; out.mx[2] = mx[2];
+		out.cnt_flag = cnt | (leaf <= split ? 0x80000000u : 0u);
+		out.cost = fminf(leaf, split);
+		bin[node] = out;
+		node = parent_inner[node];
+	}
+}
+
+// ---------------------------------------------------------------------------------- 8 collapse
+
+struct WideJob { int bin; uint32_t wide; };
+
+struct Cand {
+	int ref;          // binary child: >= 0 inner, < 0 leaf ~slot
+	float mn[3], mx[3];
+	float area;       // > 0 only if the child may still be opened
+};
+
+__device__ __forceinline__ void load_cand(Cand &c, int ref, const DevTri *tris, const BinNode *bin)
+{
+	c.ref = ref;
+	if (ref < 0) {
+		tri_box(tris, (uint32_t)~ref, c.mn, c.mx);
+		c.area = -1.0f;
+	} else {
+		const BinNode b = bin[ref];
+		c.mn[0] = b.mn[0]; c.mn[1] = b.mn[1]; c.mn[2] = b.mn[2];
+		c.mx[0] = b.mx[0]; c.mx[1] = b.mx[1]; c.mx[2] = b.mx[2];
+		c.area = (b.cnt_flag & 0x80000000u) ? -1.0f : half_area(c.mn, c.mx);
+	}
+}
+
+// One thread per 4-wide node of this level: open the binary node, then twice more open
+// the largest-area child that is still an inner node, and write the 128 B node. Inner
+// children get their indices from an atomic counter and go to the next level's queue.
+__global__ void k_collapse_level(const WideJob *jobs, uint32_t num_jobs, const int *left, const int *right,
+	const uint32_t *range_first, const uint32_t *range_last, const BinNode *bin, DevTri *tris, DevNode *nodes,
+	WideJob *next_jobs, uint32_t *next_count, uint32_t next_base)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= num_jobs) return;
+	const WideJob job = jobs[j];
+	Cand c[4];
+	int nc;
+	if (bin[job.bin].cnt_flag & 0x80000000u) {
+		// the whole (sub)tree is one leaf: only happens for the root of a tiny scene
+		load_cand(c[0], job.bin, tris, bin);
+		nc = 1;
+	} else {
+		load_cand(c[0], left[job.bin], tris, bin);
+		load_cand(c[1], right[job.bin], tris, bin);
+		nc = 2;
+		for (int round = 0; round < 2; round++) {
+			int best = -1;
+			float best_area = 0.0f;
+			for (int k = 0; k < nc; k++) if (c[k].area > best_area) { best_area = c[k].area; best = k; }
+			if (best < 0) break;
+			const int open = c[best].ref;
+			load_cand(c[best], left[open], tris, bin);
+			load_cand(c[nc], right[open], tris, bin);
+			nc++;
+		}
+	}
+	DevNode out;
+	for (int k = 0; k < 4; k++) {
+		out.pad[k] = 0;
+		if (k >= nc) {
+			out.bx[0][k] = out.by[0][k] = out.bz[0][k] = +1.0f;   // inverted = never hit (rtk.c:1612-1620)
+			out.bx[1][k] = out.by[1][k] = out.bz[1][k] = -1.0f;
+			out.child[k] = RTK_REF_NONE;
+			continue;
+		}
+		out.bx[0][k] = c[k].mn[0]; out.bx[1][k] = c[k].mx[0];
+		out.by[0][k] = c[k].mn[1]; out.by[1][k] = c[k].mx[1];
+		out.bz[0][k] = c[k].mn[2]; out.bz[1][k] = c[k].mx[2];
+		const int ref = c[k].ref;
+		if (ref < 0) {
+			const uint32_t s = (uint32_t)~ref;
+			tris[s].spare = 1u;
+			tris[s].flags = RTK_TRI_LAST;
+			out.child[k] = RTK_REF_LEAF | s;
+		} else if (bin[ref].cnt_flag & 0x80000000u) {
+			const uint32_t first = range_first[ref], last = range_last[ref];
+			tris[first].spare = last - first + 1u;
+			tris[last].flags = RTK_TRI_LAST;
+			out.child[k] = RTK_REF_LEAF | first;
+		} else {
+			const uint32_t slot = atomicAdd(next_count, 1u);
+			next_jobs[slot].bin = ref;
+			next_jobs[slot].wide = next_base + slot;
+			out.child[k] = next_base + slot;
+		}
+	}
+	nodes[job.wide] = out;
+}
+
+// ---------------------------------------------------------------------------------- host side
+
+template <typename T>
+struct DevBuf {
+	T *p = nullptr;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	bool alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
+	T *release() { T *r = p; p = nullptr; return r; }
+};
+
+float env_float(const char *name, float def)
+{
+	const char *s = getenv(name);
+	return s && *s ? (float)atof(s) : def;
+}
+
+bool exclusive_scan_u32(uint32_t *d, size_t n)
+{
+	const size_t per_block = SCAN_BLOCK * SCAN_ITEMS;
+	const size_t blocks = (n + per_block - 1) / per_block;
+	DevBuf<uint32_t> sums;
+	if (!sums.alloc(blocks)) return false;
+	hipLaunchKernelGGL(k_scan_block, dim3((unsigned)blocks), dim3(SCAN_BLOCK), 0, 0, d, n, sums.p);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, 0, sums.p, (uint32_t)blocks);
+	hipLaunchKernelGGL(k_scan_add, dim3((unsigned)blocks), dim3(SCAN_BLOCK), 0, 0, d, n, sums.p);
+	return hipDeviceSynchronize() == hipSuccess;   // sums is freed on return
+}
+
+// Host decode of a mesh that uses callbacks (rtk.c:1030-1033, 1074-1077), 128 triangles per call.
+void decode_mesh_on_host(const rtk_mesh *m, float *pos9, uint32_t *vidx3)
+{
+	size_t offset = 0, left = m->num_triangles;
+	while (left) {
+		const size_t chunk = left > 128 ? 128 : left;
+		uint32_t indices[128 * 3];
+		rtk_vec3 verts[128 * 3 + 1];
+		if (m->index_cb) m->index_cb(m->index_cb_user, m, indices, offset, chunk);
+		else if (m->index.data) {
+			const size_t stride = m->index.stride ? m->index.stride : (m->index.type == RTK_TYPE_U16 ? 6 : 12);
+			for (size_t i = 0; i < chunk; i++) {
+				const char *p = (const char *)m->index.data + (offset + i) * stride;
+				for (int c = 0; c < 3; c++)
+					indices[3 * i + c] = m->index.type == RTK_TYPE_U16 ? ((const uint16_t *)p)[c] : ((const uint32_t *)p)[c];
+			}
+		} else {
+			for (size_t i = 0; i < chunk; i++) for (int c = 0; c < 3; c++) indices[3 * i + c] = (uint32_t)(offset + i) * 3u + c;
+		}
+		if (m->position_cb) m->position_cb(m->position_cb_user, m, verts, indices, chunk);
+		else {
+			const bool f64 = m->position.type == RTK_TYPE_F64;
+			const size_t stride = m->position.stride ? m->position.stride : (f64 ? 24 : 12);
+			for (size_t i = 0; i < 3 * chunk; i++) {
+				const char *p = (const char *)m->position.data + (size_t)indices[i] * stride;
+				if (f64) { verts[i].x = (float)((const double *)p)[0]; verts[i].y = (float)((const double *)p)[1]; verts[i].z = (float)((const double *)p)[2]; }
+				else { verts[i].x = ((const float *)p)[0]; verts[i].y = ((const float *)p)[1]; verts[i].z = ((const float *)p)[2]; }
+			}
+		}
+		for (size_t i = 0; i < 3 * chunk; i++) {
+			pos9[3 * (3 * offset + i) + 0] = verts[i].x;
+			pos9[3 * (3 * offset + i) + 1] = verts[i].y;
+			pos9[3 * (3 * offset + i) + 2] = verts[i].z;
+			vidx3[3 * offset + i] = indices[i];
+		}
+		offset += chunk;
+		left -= chunk;
+	}
+}
+
+#define BUILD_CHECK(expr)                                                                               \
+	do {                                                                                                \
+		hipError_t e_ = (expr);                                                                         \
+		if (e_ != hipSuccess) {                                                                         \
+			rtk_set_error("device build: %s failed: %s (line %d)", #expr, hipGetErrorString(e_), __LINE__); \
+			return nullptr;                                                                             \
+		}                                                                                               \
+	} while (0)
+
+rtk_dev_scene *build_tiny(const rtk_scene_desc *desc, const std::vector<uint64_t> &mesh_base, const std::vector<float> &pos,
+	const std::vector<uint32_t> &vidx)
+{
+	// 0 or 1 triangle: no radix tree to build; one root node, at most one leaf.
+	HostBvh h;
+	h.mesh_base = mesh_base;
+	h.max_depth = 1;
+	DevNode root;
+	memset(&root, 0, sizeof(root));
+	for (int k = 0; k < 4; k++) {
+		root.bx[0][k] = root.by[0][k] = root.bz[0][k] = +1.0f;
+		root.bx[1][k] = root.by[1][k] = root.bz[1][k] = -1.0f;
+		root.child[k] = RTK_REF_NONE;
+	}
+	const size_t n = pos.size() / 9;
+	if (n == 1) {
+		DevTri t;
+		memset(&t, 0, sizeof(t));
+		for (int a = 0; a < 3; a++) { t.v0[a] = pos[a]; t.v1[a] = pos[3 + a]; t.v2[a] = pos[6 + a]; }
+		t.prim = 0; t.flags = RTK_TRI_LAST; t.spare = 1;
+		h.tris.push_back(t);
+		for (int c = 0; c < 3; c++) h.vertex_index.push_back(vidx[c]);
+		uint32_t mesh = 0;
+		while (mesh + 1 < mesh_base.size() - 1 && mesh_base[mesh + 1] == 0) mesh++;
+		h.slot_mesh.push_back(mesh);
+		h.slot_tri.push_back(0);
+		float mn[3], mx[3];
+		for (int a = 0; a < 3; a++) { mn[a] = std::min(std::min(t.v0[a], t.v1[a]), t.v2[a]); mx[a] = std::max(std::max(t.v0[a], t.v1[a]), t.v2[a]); }
+		root.bx[0][0] = mn[0]; root.bx[1][0] = mx[0];
+		root.by[0][0] = mn[1]; root.by[1][0] = mx[1];
+		root.bz[0][0] = mn[2]; root.bz[1][0] = mx[2];
+		root.child[0] = RTK_REF_LEAF | 0u;
+	}
+	h.nodes.push_back(root);
+	(void)desc;
+	return rtk_dev_scene_from_host_bvh(h);
+}
+
+} // namespace
+
+// =====================================================================================
+// rtk_dev_scene_build
+// =====================================================================================
+
+extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
+{
+	if (!desc || (!desc->meshes && desc->num_meshes)) { rtk_set_error("rtk_dev_scene_build: NULL scene description"); return nullptr; }
+	std::vector<uint64_t> mesh_base(desc->num_meshes + 1, 0);
+	for (size_t m = 0; m < desc->num_meshes; m++) mesh_base[m + 1] = mesh_base[m] + desc->meshes[m].num_triangles;
+	const uint64_t n64 = mesh_base.back();
+	if (n64 >= 0x3ffffff0ull) { rtk_set_error("rtk_dev_scene_build: more than 2^30 triangles"); return nullptr; }
+	const uint32_t n = (uint32_t)n64;
+	if (desc->log_fn) desc->log_fn(desc->log_user, nullptr, "rtk_amd: device LBVH build");
+
+	int device = 0;
+	hipDeviceProp_t prop;
+	BUILD_CHECK(hipGetDevice(&device));
+	BUILD_CHECK(hipGetDeviceProperties(&prop, device));
+
+	// ---- 1 ingest ------------------------------------------------------------------
+	DevBuf<float> in_pos;
+	DevBuf<uint32_t> in_vidx;
+	if (!in_pos.alloc(9 * (size_t)n) || !in_vidx.alloc(3 * (size_t)n)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+	std::vector<float> tiny_pos;
+	std::vector<uint32_t> tiny_vidx;
+	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
+		const rtk_mesh *m = &desc->meshes[mi];
+		const size_t nt = m->num_triangles;
+		if (nt == 0) continue;
+		const uint32_t base = (uint32_t)mesh_base[mi];
+		if (m->position_cb || m->index_cb || n < 2) {
+			std::vector<float> pos9(9 * nt);
+			std::vector<uint32_t> vidx3(3 * nt);
+			decode_mesh_on_host(m, pos9.data(), vidx3.data());
+			if (n < 2) { tiny_pos = pos9; tiny_vidx = vidx3; continue; }
+			BUILD_CHECK(hipMemcpy(in_pos.p + 9 * (size_t)base, pos9.data(), pos9.size() * 4, hipMemcpyHostToDevice));
+			BUILD_CHECK(hipMemcpy(in_vidx.p + 3 * (size_t)base, vidx3.data(), vidx3.size() * 4, hipMemcpyHostToDevice));
+			continue;
+		}
+		if (!m->position.data) { rtk_set_error("rtk_dev_scene_build: mesh %zu has no positions", mi); return nullptr; }
+		// raw buffers go to the device as they are; the decode runs there
+		const bool f64 = m->position.type == RTK_TYPE_F64;
+		const size_t pstride = m->position.stride ? m->position.stride : (f64 ? 24 : 12);
+		int idx_kind = 0;
+		size_t istride = 0;
+		uint64_t max_vertex = 3ull * nt - 1;
+		DevBuf<char> d_idx;
+		if (m->index.data) {
+			const bool u16 = m->index.type == RTK_TYPE_U16;
+			if (!u16 && m->index.type != RTK_TYPE_U32 && m->index.type != RTK_TYPE_DEFAULT) { rtk_set_error("rtk_dev_scene_build: bad index type"); return nullptr; }
+			idx_kind = u16 ? 1 : 2;
+			istride = m->index.stride ? m->index.stride : (u16 ? 6 : 12);
+			max_vertex = 0;
+			for (size_t i = 0; i < nt; i++) {
+				const char *p = (const char *)m->index.data + i * istride;
+				for (int c = 0; c < 3; c++) {
+					const uint64_t v = u16 ? ((const uint16_t *)p)[c] : ((const uint32_t *)p)[c];
+					if (v > max_vertex) max_vertex = v;
+				}
+			}
+			const size_t ibytes = (nt - 1) * istride + (u16 ? 6 : 12);
+			if (!d_idx.alloc(ibytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+			BUILD_CHECK(hipMemcpy(d_idx.p, m->index.data, ibytes, hipMemcpyHostToDevice));
+		}
+		const size_t pbytes = (size_t)max_vertex * pstride + (f64 ? 24 : 12);
+		DevBuf<char> d_pos;
+		if (!d_pos.alloc(pbytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+		BUILD_CHECK(hipMemcpy(d_pos.p, m->position.data, pbytes, hipMemcpyHostToDevice));
+		const unsigned iblocks = (unsigned)((nt + 255) / 256);
+		if (idx_kind == 0) launch_ingest<0>(f64, iblocks, d_pos.p, pstride, d_idx.p, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
+		else if (idx_kind == 1) launch_ingest<1>(f64, iblocks, d_pos.p, pstride, d_idx.p, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
+		else launch_ingest<2>(f64, iblocks, d_pos.p, pstride, d_idx.p, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
+		BUILD_CHECK(hipGetLastError());
+		BUILD_CHECK(hipDeviceSynchronize());   // d_pos/d_idx are released at scope end
+	}
+	if (n < 2) return build_tiny(desc, mesh_base, tiny_pos, tiny_vidx);
+
+	BuildParams bp;
+	bp.cost_tri = env_float("RTK_AMD_SAH_CT", 1.0f);
+	bp.cost_node = env_float("RTK_AMD_SAH_CN", 1.0f);
+	bp.max_leaf = (uint32_t)env_float("RTK_AMD_MAX_LEAF", 8.0f);
+	if (bp.max_leaf < 1) bp.max_leaf = 1;
+	if (bp.max_leaf > 63) bp.max_leaf = 63;     // 6-bit count in the blob's leaf header (rtk.c:188)
+
+	// ---- 2 bounds, 3 morton -----------------------------------------------------------
+	DevBuf<uint32_t> d_bounds;
+	DevBuf<unsigned long long> keys_a, keys_b;
+	DevBuf<uint32_t> vals_a, vals_b;
+	if (!d_bounds.alloc(6) || !keys_a.alloc(n) || !keys_b.alloc(n) || !vals_a.alloc(n) || !vals_b.alloc(n)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+	{
+		const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+		BUILD_CHECK(hipMemcpy(d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice));
+		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + SORT_BLOCK - 1) / SORT_BLOCK, (size_t)prop.multiProcessorCount * 8);
+		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(SORT_BLOCK), 0, 0, in_pos.p, n, d_bounds.p);
+		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos.p, n, d_bounds.p, keys_a.p, vals_a.p);
+		BUILD_CHECK(hipGetLastError());
+	}
+
+	// ---- 4 sort ------------------------------------------------------------------------
+	{
+		const uint32_t num_units = (n + SORT_WAVE_ITEMS - 1u) / SORT_WAVE_ITEMS;
+		const unsigned blocks = (num_units + (SORT_BLOCK / 64) - 1) / (SORT_BLOCK / 64);
+		DevBuf<uint32_t> hist;
+		if (!hist.alloc(256 * (size_t)num_units)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+		unsigned long long *kin = keys_a.p, *kout = keys_b.p;
+		uint32_t *vin = vals_a.p, *vout = vals_b.p;
+		for (uint32_t shift = 0; shift < 64; shift += 8) {   // 63 key bits -> 8 passes; an even count leaves the result in *_a
+			hipLaunchKernelGGL(k_sort_hist, dim3(blocks), dim3(SORT_BLOCK), 0, 0, kin, n, shift, num_units, hist.p);
+			if (!exclusive_scan_u32(hist.p, 256 * (size_t)num_units)) { rtk_set_error("device build: scan failed: %s", hipGetErrorString(hipGetLastError())); return nullptr; }
+			hipLaunchKernelGGL(k_sort_scatter, dim3(blocks), dim3(SORT_BLOCK), 0, 0, kin, vin, n, shift, num_units, hist.p, kout, vout);
+			BUILD_CHECK(hipGetLastError());
+			std::swap(kin, kout);
+			std::swap(vin, vout);
+		}
+		BUILD_CHECK(hipDeviceSynchronize());
+	}
+
+	// ---- 5 emit: final triangle records in Morton order ----------------------------------
+	rtk_dev_scene *ds = new rtk_dev_scene();
+	ds->device = device;
+	ds->num_cus = prop.multiProcessorCount;
+	ds->mesh_base = mesh_base;
+	auto fail = [&](const char *what) -> rtk_dev_scene * {
+		rtk_set_error("device build: %s: %s", what, hipGetErrorString(hipGetLastError()));
+		rtk_dev_scene_free(ds);
+		return nullptr;
+	};
+	auto dev_alloc = [&](size_t bytes) -> void * {
+		void *p = nullptr;
+		if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+		ds->allocs.push_back(p);
+		ds->total_bytes += bytes;
+		return p;
+	};
+	DevTri *d_tris = (DevTri *)dev_alloc((size_t)n * sizeof(DevTri));
+	uint32_t *d_vertex_index = (uint32_t *)dev_alloc(3 * (size_t)n * 4);
+	uint32_t *d_prim_slot = (uint32_t *)dev_alloc((size_t)n * 4);
+	uint32_t *d_slot_mesh = (uint32_t *)dev_alloc((size_t)n * 4);
+	uint32_t *d_slot_tri = (uint32_t *)dev_alloc((size_t)n * 4);
+	DevBuf<unsigned long long> d_mesh_base;
+	if (!d_tris || !d_vertex_index || !d_prim_slot || !d_slot_mesh || !d_slot_tri || !d_mesh_base.alloc(mesh_base.size())) return fail("out of device memory");
+	{
+		std::vector<unsigned long long> mb(mesh_base.begin(), mesh_base.end());
+		if (hipMemcpy(d_mesh_base.p, mb.data(), mb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos.p, in_vidx.p, vals_a.p, n, d_mesh_base.p,
+			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
+		if (hipGetLastError() != hipSuccess) return fail("emit launch");
+	}
+
+	// ---- 6 karras, 7 refit ------------------------------------------------------------------
+	DevBuf<int> d_left, d_right, d_parent_inner, d_parent_leaf;
+	DevBuf<uint32_t> d_first, d_last, d_arrive;
+	DevBuf<BinNode> d_bin;
+	if (!d_left.alloc(n) || !d_right.alloc(n) || !d_parent_inner.alloc(n) || !d_parent_leaf.alloc(n) || !d_first.alloc(n) ||
+		!d_last.alloc(n) || !d_arrive.alloc(n) || !d_bin.alloc(n)) return fail("out of device memory");
+	if (hipMemset(d_arrive.p, 0, (size_t)n * 4) != hipSuccess) return fail("memset");
+	hipLaunchKernelGGL(k_karras, dim3((n + 255u) / 256u), dim3(256), 0, 0, keys_a.p, (int)n, d_left.p, d_right.p, d_parent_inner.p,
+		d_parent_leaf.p, d_first.p, d_last.p);
+	hipLaunchKernelGGL(k_refit, dim3((n + 255u) / 256u), dim3(256), 0, 0, d_tris, (int)n, d_left.p, d_right.p, d_parent_inner.p,
+		d_parent_leaf.p, d_arrive.p, d_bin.p, bp);
+	if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("karras/refit");
+
+	// ---- 8 collapse, one launch per level of the 4-wide tree -----------------------------------
+	DevBuf<DevNode> d_nodes_tmp;       // worst case one wide node per binary inner node
+	DevBuf<WideJob> jobs_a, jobs_b;
+	DevBuf<uint32_t> d_next;
+	if (!d_nodes_tmp.alloc(n) || !jobs_a.alloc(n) || !jobs_b.alloc(n) || !d_next.alloc(1)) return fail("out of device memory");
+	uint32_t total_nodes = 1, level_count = 1, depth = 0;
+	{
+		const WideJob rootjob = { 0, 0u };
+		if (hipMemcpy(jobs_a.p, &rootjob, sizeof(rootjob), hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
+	}
+	WideJob *jin = jobs_a.p, *jout = jobs_b.p;
+	while (level_count) {
+		depth++;
+		if (hipMemset(d_next.p, 0, 4) != hipSuccess) return fail("memset");
+		hipLaunchKernelGGL(k_collapse_level, dim3((level_count + 127u) / 128u), dim3(128), 0, 0, jin, level_count, d_left.p, d_right.p,
+			d_first.p, d_last.p, d_bin.p, d_tris, d_nodes_tmp.p, jout, d_next.p, total_nodes);
+		uint32_t next = 0;
+		if (hipGetLastError() != hipSuccess || hipMemcpy(&next, d_next.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse level");
+		total_nodes += next;
+		level_count = next;
+		std::swap(jin, jout);
+		if (depth > 4096) return fail("collapse did not terminate");
+	}
+
+	// shrink the node array to what was used
+	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
+	if (!d_nodes) return fail("out of device memory");
+	if (hipMemcpy(d_nodes, d_nodes_tmp.p, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice) != hipSuccess) return fail("copy");
+	if (hipMalloc(&ds->d_counter, 8 * sizeof(unsigned long long)) != hipSuccess) return fail("out of device memory");
+	if (hipDeviceSynchronize() != hipSuccess) return fail("sync");
+
+	ds->view.nodes = d_nodes;
+	ds->view.tris = d_tris;
+	ds->view.vertex_index = d_vertex_index;
+	ds->view.prim_slot = d_prim_slot;
+	ds->view.slot_mesh = d_slot_mesh;
+	ds->view.slot_tri = d_slot_tri;
+	ds->view.num_nodes = total_nodes;
+	ds->view.num_tris = n;
+	ds->view.num_prims = n;
+	ds->max_depth = depth;
+	ds->stack_entries = 3u * depth + 1u;
+	return ds;
+}
+
+// =====================================================================================
+// export: device BVH -> reference-format blob (writer intent rtk.c:1719-1774)
+// =====================================================================================
+
+namespace {
+
+struct ExportPlan {
+	std::vector<DevNode> nodes;
+	std::vector<DevTri> tris;
+	std::vector<uint32_t> vertex_index, slot_mesh, slot_tri;
+	// per leaf (in slot order)
+	struct Leaf { uint32_t first, count; uint64_t offset; uint64_t group_byte; uint32_t num_meshes; std::vector<uint8_t> vix; };
+	std::vector<Leaf> leaves;
+	std::unordered_map<uint32_t, uint32_t> leaf_of_slot;
+	std::vector<rtk_vertex> vertices;
+	uint64_t node_off = 128, leaf_off = 0, vert_off = 0, total = 0;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
+
+bool download(const rtk_dev_scene *ds, ExportPlan &ep)
+{
+	const DevSceneView &v = ds->view;
+	ep.nodes.resize(v.num_nodes);
+	ep.tris.resize(v.num_tris);
+	ep.vertex_index.resize(3 * (size_t)v.num_tris);
+	ep.slot_mesh.resize(v.num_tris);
+	ep.slot_tri.resize(v.num_tris);
+	bool ok = hipMemcpy(ep.nodes.data(), v.nodes, ep.nodes.size() * sizeof(DevNode), hipMemcpyDeviceToHost) == hipSuccess;
+	if (v.num_tris) {
+		ok = ok && hipMemcpy(ep.tris.data(), v.tris, ep.tris.size() * sizeof(DevTri), hipMemcpyDeviceToHost) == hipSuccess;
+		ok = ok && hipMemcpy(ep.vertex_index.data(), v.vertex_index, ep.vertex_index.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+		ok = ok && hipMemcpy(ep.slot_mesh.data(), v.slot_mesh, ep.slot_mesh.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+		ok = ok && hipMemcpy(ep.slot_tri.data(), v.slot_tri, ep.slot_tri.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+	}
+	if (!ok) rtk_set_error("export: device to host copy failed: %s", hipGetErrorString(hipGetLastError()));
+	return ok;
+}
+
+// Lay out leaves and vertex groups. Leaves are visited in slot order (= Morton order), so
+// consecutive leaves are neighbours in space and share vertices of indexed meshes; a
+// vertex group (<= 256 vertices, u8 indices, rtk.c:83, 1186) is closed when the next leaf
+// would not fit.
+bool plan(ExportPlan &ep)
+{
+	std::vector<uint32_t> firsts;
+	for (const DevNode &n : ep.nodes)
+		for (int k = 0; k < 4; k++)
+			if (n.child[k] != RTK_REF_NONE && (n.child[k] & RTK_REF_LEAF)) firsts.push_back(n.child[k] & 0x7fffffffu);
+	std::sort(firsts.begin(), firsts.end());
+	firsts.erase(std::unique(firsts.begin(), firsts.end()), firsts.end());
+	ep.leaves.resize(firsts.size());
+	std::unordered_map<uint64_t, uint32_t> group;   // (mesh<<32 | vertex index) -> index in the open group
+	size_t group_start = 0;                          // in vertices
+	uint64_t leaf_bytes = 64;                        // null leaf first (rtk.c:1763-1765)
+	for (size_t li = 0; li < firsts.size(); li++) {
+		ExportPlan::Leaf &lf = ep.leaves[li];
+		lf.first = firsts[li];
+		if (lf.first >= ep.tris.size()) { rtk_set_error("export: leaf reference out of range"); return false; }
+		lf.count = ep.tris[lf.first].spare;
+		if (lf.count == 0 || lf.count > 63 || (size_t)lf.first + lf.count > ep.tris.size()) { rtk_set_error("export: leaf of %u triangles cannot be written (1..63)", lf.count); return false; }
+		ep.leaf_of_slot[lf.first] = (uint32_t)li;
+		// distinct vertices this leaf would add
+		std::vector<uint64_t> keys(3 * (size_t)lf.count);
+		for (uint32_t i = 0; i < lf.count; i++)
+			for (int c = 0; c < 3; c++)
+				keys[3 * i + c] = ((uint64_t)ep.slot_mesh[lf.first + i] << 32) | ep.vertex_index[3 * (size_t)(lf.first + i) + c];
+		size_t fresh = 0;
+		{
+			std::vector<uint64_t> uniq(keys);
+			std::sort(uniq.begin(), uniq.end());
+			uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+			for (uint64_t k : uniq) if (!group.count(k)) fresh++;
+		}
+		if (group.size() + fresh > 256) {
+			group.clear();
+			group_start = align_up(ep.vertices.size(), 4);    // 64-byte aligned groups (rtk.c:193)
+			ep.vertices.resize(group_start);
+		}
+		lf.group_byte = (uint64_t)group_start * 16u;
+		lf.vix.resize(3 * (size_t)lf.count);
+		std::vector<uint32_t> meshes;
+		for (uint32_t i = 0; i < lf.count; i++) {
+			const DevTri &t = ep.tris[lf.first + i];
+			const float *pv[3] = { t.v0, t.v1, t.v2 };
+			for (int c = 0; c < 3; c++) {
+				const uint64_t k = keys[3 * i + c];
+				auto it = group.find(k);
+				uint32_t idx;
+				if (it == group.end()) {
+					idx = (uint32_t)group.size();
+					group[k] = idx;
+					rtk_vertex v;
+					v.position.x = pv[c][0]; v.position.y = pv[c][1]; v.position.z = pv[c][2];
+					v.index = (uint32_t)k;
+					ep.vertices.push_back(v);
+				} else idx = it->second;
+				lf.vix[3 * i + c] = (uint8_t)idx;
+			}
+			const uint32_t mesh = ep.slot_mesh[lf.first + i];
+			if (std::find(meshes.begin(), meshes.end(), mesh) == meshes.end()) meshes.push_back(mesh);
+		}
+		lf.num_meshes = (uint32_t)meshes.size();
+		lf.offset = leaf_bytes;
+		leaf_bytes += align_up(8 + 8 * (size_t)((lf.count + 3u) & ~3u) + 4 * meshes.size(), 64);
+	}
+	ep.leaf_off = align_up(ep.node_off + ep.nodes.size() * 128, 128);
+	ep.vert_off = align_up(ep.leaf_off + leaf_bytes, 128);
+	ep.total = align_up(ep.vert_off + align_up(ep.vertices.size(), 4) * 16, 128);
+	return true;
+}
+
+void write_blob(const ExportPlan &ep, char *blob)
+{
+	memset(blob, 0, ep.total);
+	rtk_scene *s = (rtk_scene *)blob;
+	static const char magic[8] = { 0, 'R', 'T', 'K', '\r', '\n', 0x1a, '\n' };
+	memcpy(s->magic, magic, 8);
+	s->endian = 0xaabb; s->sizeof_real = 4; s->pad_0 = 0; s->version = 1; s->pad_1 = 0;
+	s->size_in_bytes = ep.total; s->node_offset = ep.node_off; s->leaf_offset = ep.leaf_off; s->vertex_offset = ep.vert_off;
+	for (size_t i = 0; i < ep.nodes.size(); i++) {
+		const DevNode &n = ep.nodes[i];
+		char *dst = blob + ep.node_off + i * 128;
+		memcpy(dst, n.bx, 96);
+		uint64_t ptr[4];
+		for (int k = 0; k < 4; k++) {
+			const uint32_t r = n.child[k];
+			if (r == RTK_REF_NONE) ptr[k] = ep.leaf_off | 1u;                               // null leaf (rtk.c:1619, tagged: B19)
+			else if (r & RTK_REF_LEAF) ptr[k] = (ep.leaf_off + ep.leaves[ep.leaf_of_slot.at(r & 0x7fffffffu)].offset) | 1u;
+			else ptr[k] = ep.node_off + (uint64_t)r * 128u;
+		}
+		memcpy(dst + 96, ptr, 32);
+	}
+	for (const ExportPlan::Leaf &lf : ep.leaves) {
+		char *dst = blob + ep.leaf_off + lf.offset;
+		const uint64_t info = (uint64_t)lf.count | (ep.vert_off + lf.group_byte);
+		memcpy(dst, &info, 8);
+		const size_t n4 = (lf.count + 3u) & ~3u;
+		uint32_t *table = (uint32_t *)(dst + 8 + 8 * n4);
+		uint32_t nm = 0;
+		for (uint32_t i = 0; i < lf.count; i++) {
+			uint8_t *rec = (uint8_t *)dst + 8 + 8 * (size_t)i;
+			rec[0] = lf.vix[3 * i]; rec[1] = lf.vix[3 * i + 1]; rec[2] = lf.vix[3 * i + 2];
+			const uint32_t mesh = ep.slot_mesh[lf.first + i];
+			uint32_t k = 0;
+			for (; k < nm; k++) if (table[k] == mesh) break;
+			if (k == nm) table[nm++] = mesh;
+			rec[3] = (uint8_t)k;
+			memcpy(rec + 4, &ep.slot_tri[lf.first + i], 4);
+		}
+	}
+	if (!ep.vertices.empty()) memcpy(blob + ep.vert_off, ep.vertices.data(), ep.vertices.size() * 16);
+}
+
+// one export plan is cached per scene between export_size and export
+std::unordered_map<const rtk_dev_scene *, ExportPlan *> g_plans;
+
+ExportPlan *get_plan(const rtk_dev_scene *ds)
+{
+	auto it = g_plans.find(ds);
+	if (it != g_plans.end()) return it->second;
+	ExportPlan *ep = new ExportPlan();
+	if (!download(ds, *ep) || !plan(*ep)) { delete ep; return nullptr; }
+	g_plans[ds] = ep;
+	return ep;
+}
+
+void drop_plan(const rtk_dev_scene *ds)
+{
+	auto it = g_plans.find(ds);
+	if (it != g_plans.end()) { delete it->second; g_plans.erase(it); }
+}
+
+} // namespace
+
+void rtk_export_forget(const rtk_dev_scene *ds) { drop_plan(ds); }
+
+extern "C" size_t rtk_dev_scene_export_size(const rtk_dev_scene *ds)
+{
+	if (!ds) { rtk_set_error("rtk_dev_scene_export_size: NULL scene"); return 0; }
+	ExportPlan *ep = get_plan(ds);
+	return ep ? (size_t)ep->total : 0;
+}
+
+extern "C" rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *ds, void *buffer, size_t size)
+{
+	if (!ds || !buffer) { rtk_set_error("rtk_dev_scene_export: NULL argument"); return nullptr; }
+	ExportPlan *ep = get_plan(ds);
+	if (!ep) return nullptr;
+	if (size < ep->total) { rtk_set_error("rtk_dev_scene_export: buffer too small (%zu < %llu)", size, (unsigned long long)ep->total); return nullptr; }
+	write_blob(*ep, (char *)buffer);
+	drop_plan(ds);
+	return (rtk_scene *)buffer;
+}
+
+// =====================================================================================
+// rtk.h build API (reference rtk.h:119-127) on top of the device build
+// =====================================================================================
+//
+// The reference hands the caller a graph of CPU tasks to schedule (rtk.c:1362-1507). Here the
+// parallelism is inside the GPU, so the graph has exactly one task: running it performs the
+// whole device build. Callers that loop "while tasks remain: rtk_run_task" work unchanged.
+
+struct rtk_build {
+	rtk_scene_desc desc;
+	rtk_dev_scene *scene;
+	bool done;
+};
+
+static void build_task_fn(const rtk_task *task, rtk_task_ctx *)
+{
+	rtk_build *b = task->build;
+	if (b->done) return;
+	b->scene = rtk_dev_scene_build(&b->desc);
+	b->done = true;
+}
+
+extern "C" rtk_build *rtk_start_build(const rtk_scene_desc *desc, rtk_task *first_task)
+{
+	if (!desc) { rtk_set_error("rtk_start_build: NULL description"); return nullptr; }
+	rtk_build *b = new rtk_build();
+	b->desc = *desc;              // by value; meshes stay borrowed (rtk.c:1661)
+	b->scene = nullptr;
+	b->done = false;
+	if (first_task) {
+		first_task->build = b;    // rtk.c:1679-1681
+		first_task->fn = &build_task_fn;
+		first_task->cost = 0.0;
+		first_task->index = 0;
+		first_task->arg = 0;
+	} else {
+		rtk_task t;
+		memset(&t, 0, sizeof(t));
+		t.build = b;
+		t.fn = &build_task_fn;
+		build_task_fn(&t, nullptr);   // the inline path the reference leaves as a TODO (rtk.c:1682-1688, B8)
+		if (!b->scene) { delete b; return nullptr; }
+	}
+	return b;
+}
+
+extern "C" size_t rtk_run_task(const rtk_task *task, rtk_task *queue, size_t queue_size)
+{
+	(void)queue; (void)queue_size;
+	if (!task || !task->fn) return 0;
+	task->fn(task, nullptr);
+	return 0;                     // no follow-up tasks
+}
+
+extern "C" size_t rtk_get_build_size(const rtk_build *build)
+{
+	if (!build || !build->scene) { rtk_set_error("rtk_get_build_size: build has not run (or failed)"); return 0; }
+	return rtk_dev_scene_export_size(build->scene);
+}
+
+extern "C" rtk_scene *rtk_finish_build_to(rtk_build *build, void *buffer, size_t size)
+{
+	if (!build || !build->scene || !buffer) { rtk_set_error("rtk_finish_build_to: build has not run (or failed)"); return nullptr; }
+	const size_t need = rtk_dev_scene_export_size(build->scene);
+	if (need == 0 || size < need) return nullptr;             // build stays alive (rtk.c:1735)
+	rtk_scene *s = rtk_dev_scene_export(build->scene, buffer, size);
+	if (!s) return nullptr;
+	rtk_cache_adopt(s, build->scene);                         // the device copy stays resident for rtk_trace_rays
+	delete build;                                             // rtk.c:1771
+	return s;
+}
+
+extern "C" rtk_scene *rtk_finish_build(rtk_build *build)
+{
+	if (!build) return nullptr;
+	const size_t need = build->scene ? rtk_dev_scene_export_size(build->scene) : 0;
+	void *buffer = need ? aligned_alloc(128, align_up(need, 128)) : nullptr;
+	if (!buffer) {                                            // rtk.c:1779-1783: free the build, return NULL
+		if (build->scene) rtk_dev_scene_free(build->scene);
+		delete build;
+		return nullptr;
+	}
+	rtk_scene *s = rtk_finish_build_to(build, buffer, need);
+	if (!s) { free(buffer); if (build->scene) rtk_dev_scene_free(build->scene); delete build; }
+	return s;
+}
+
+extern "C" rtk_scene *rtk_build_scene(const rtk_scene_desc *desc)
+{
+	rtk_build *b = rtk_start_build(desc, nullptr);            // rtk.c:1788-1792
+	return b ? rtk_finish_build(b) : nullptr;
+}
+
+extern "C" void rtk_free_scene(rtk_scene *scene)
+{
+	if (!scene) return;
+	rtk_amd_forget_scene(scene);                              // drops the resident device copy
+	free(scene);                                              // rtk.c:1794-1797
+}

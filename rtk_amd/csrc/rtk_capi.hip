@@ -49,9 +49,12 @@ extern "C" rtk_dev_scene *rtk_dev_scene_upload(const rtk_scene *scene)
 	return rtk_dev_scene_from_host_bvh(h);
 }
 
+void rtk_export_forget(const rtk_dev_scene *ds);   // rtk_build.hip
+
 extern "C" void rtk_dev_scene_free(rtk_dev_scene *ds)
 {
 	if (!ds) return;
+	rtk_export_forget(ds);
 	for (void *p : ds->allocs) (void)hipFree(p);
 	if (ds->d_counter) (void)hipFree(ds->d_counter);
 	if (ds->d_spill) (void)hipFree(ds->d_spill);

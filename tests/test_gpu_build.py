@@ -1,0 +1,175 @@
+"""GPU tests of the device LBVH builder (rtk_dev_scene_build / rtk_build_scene and the task
+API) -- structure through the exported blob, results against the golden fixtures from the
+real reference and bit-for-bit against the CPU oracle traversing the exported blob."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rtk_amd import synth
+from rtk_amd.types import RAY_DTYPE, Task
+from tests.util import compare_hits, compare_hits_struct, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from rtk_amd import api
+    api.lib()
+    return api
+
+
+def _as_blob(oracle, arr):
+    b = oracle._aligned_bytes(arr.size)
+    b[:] = arr
+    return oracle.Blob(b)
+
+
+def _same_as_oracle(oracle, blob, ds, rays, what):
+    hits, mask, rec = ds.trace(rays)
+    ohits, omask = oracle.trace(blob, rays)
+    st = compare_hits(mask, hits["mesh_index"], hits["triangle_index"], hits["t"], hits["u"], hits["v"],
+                      omask, ohits["mesh_index"], ohits["triangle_index"], ohits["t"], ohits["u"], ohits["v"], what)
+    assert st["bit_exact"] == 1.0, what
+    assert (hits["vertex"]["index"][mask] == ohits["vertex"]["index"][omask]).all()
+    return hits, mask, rec
+
+
+def test_config1_device_build(api, oracle, golden_dir):
+    tris = synth.scene_for_config(1)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    info = ds.info()
+    assert info["num_triangles"] == 10000 and info["num_nodes"] > 100 and 2 <= info["max_depth"] < 40
+    blob = _as_blob(oracle, ds.export_blob())
+    rc, counts = oracle.validate_blob(blob)
+    assert rc == 0 and counts["tris"] == 10000 and counts["nodes"] == info["num_nodes"]
+    rays = synth.rays_config1(65536)
+    hits, mask, rec = _same_as_oracle(oracle, blob, ds, rays, "lbvh vs oracle on exported blob")
+    compare_hits_struct(hits, mask, load_golden(golden_dir, "cfg1_full.npz"), "lbvh vs reference fixture")
+    # the exported blob uploaded again gives the same BVH
+    ds2 = api.DeviceScene.upload(blob)
+    assert ds2.trace(rays, full=False).tobytes() == rec.tobytes()
+
+
+def test_every_triangle_is_hit_by_its_own_ray(api):
+    """Completeness of the build: a ray aimed at each triangle's centroid from just in front of it
+    along its normal must report a hit no farther than that triangle."""
+    tris = synth.scene_for_config(1).reshape(-1, 3, 3).astype(np.float64)
+    ds = api.DeviceScene.build([dict(positions=synth.scene_for_config(1))])
+    c = tris.mean(axis=1)
+    nrm = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    rays = np.zeros(len(tris), RAY_DTYPE)
+    rays["origin"] = (c + 1e-3 * nrm).astype(np.float32)
+    rays["direction"] = (-nrm).astype(np.float32)
+    rays["min_t"] = 0
+    rays["max_t"] = 1.0
+    rec = ds.trace(rays, full=False)
+    assert (rec["prim"] != 0xFFFFFFFF).all()
+    assert (rec["t"] <= 1.01e-3).all()
+    own = rec["prim"] == np.arange(len(tris))
+    assert own.mean() > 0.99        # the rest are overlapping neighbours that are even closer
+
+
+def test_edge_scene_indexed_multi_mesh(api, oracle, golden_dir):
+    """Mesh 0 as u16-indexed float64 positions, mesh 1 as u32-indexed float32: same hits as the fixture."""
+    g = load_golden(golden_dir, "edge_cases.npz")
+    rays = np.ascontiguousarray(g["rays"]).view(RAY_DTYPE).reshape(-1)
+    t0 = g["tris"][g["mesh"] == 0].reshape(-1, 3)
+    t1 = g["tris"][g["mesh"] == 1].reshape(-1, 3)
+    v0, inv0 = np.unique(t0, axis=0, return_inverse=True)
+    v1, inv1 = np.unique(t1, axis=0, return_inverse=True)
+    meshes = [dict(positions=v0.astype(np.float64), indices=inv0.reshape(-1, 3).astype(np.uint16)),
+              dict(positions=v1.astype(np.float32), indices=inv1.reshape(-1, 3).astype(np.uint32))]
+    ds = api.DeviceScene.build(meshes)
+    assert list(ds.mesh_base()) == [0, 8, 10]
+    blob = _as_blob(oracle, ds.export_blob())
+    assert oracle.validate_blob(blob)[0] == 0
+    hits, mask, rec = _same_as_oracle(oracle, blob, ds, rays, "edge lbvh")
+    compare_hits_struct(hits, mask, g, "edge lbvh vs reference fixture")
+    # vertex indices reported in a hit are the caller's
+    i = 0
+    assert mask[i] and set(hits["vertex"]["index"][i]) == set(inv0.reshape(-1, 3)[hits["triangle_index"][i]])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 17])
+def test_tiny_scenes(api, oracle, n):
+    tris = synth.triangle_soup(max(n, 1), 0.5, seed=9)[:3 * n]
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    assert ds.info()["num_triangles"] == n
+    rays = synth.rays_config1(2048)
+    rec = ds.trace(rays, full=False)
+    if n == 0:
+        assert (rec["prim"] == 0xFFFFFFFF).all()
+        return
+    blobs = oracle.leaf_chain_blobs(tris.reshape(-1, 3, 3))
+    ohits, omask = oracle.trace_chain(blobs, rays)
+    assert ((rec["prim"] != 0xFFFFFFFF) == omask).all()
+    assert (rec["prim"][omask] == ohits["triangle_index"][omask]).all()
+    assert np.allclose(rec["t"][omask], ohits["t"][omask], rtol=1e-5, atol=0)
+
+
+def test_rtk_build_scene_entry_point(api, oracle, golden_dir):
+    """The reference's own entry points: rtk_build_scene -> rtk_trace_rays / rtk_trace_ray -> rtk_free_scene."""
+    tris = synth.scene_for_config(1)
+    scene, keep = api.build_scene([dict(positions=tris)])
+    try:
+        blob = _as_blob(oracle, api.scene_bytes(scene))
+        assert oracle.validate_blob(blob)[0] == 0
+        g = load_golden(golden_dir, "cfg1_full.npz")
+        rays = synth.rays_config1(65536)[:4096]
+        hits, mask = api.trace_rays(scene, rays)
+        gs = {k: g[k][:4096] for k in ("hit_mask", "hit_mesh", "hit_tri", "hit_t", "hit_u", "hit_v")}
+        compare_hits_struct(hits, mask, gs, "rtk_build_scene + rtk_trace_rays")
+        h = api.trace_ray(scene, rays[0])
+        assert (h is not None) == bool(g["hit_mask"][0])
+    finally:
+        api.free_scene(scene)
+
+
+def test_task_api_shape(api, oracle):
+    """rtk_start_build(desc, &task) / rtk_run_task / rtk_get_build_size / rtk_finish_build_to (rtk.h:119-123)."""
+    from rtk_amd.types import MeshSet
+    L = api.lib()
+    ms = MeshSet([dict(positions=synth.scene_for_config(1))])
+    first = Task()
+    b = L.rtk_start_build(C.byref(ms.desc), C.byref(first))
+    assert b and first.build == b and first.fn
+    assert L.rtk_get_build_size(b) == 0                      # nothing has run yet
+    queue = (Task * 128)()
+    assert L.rtk_run_task(C.byref(first), queue, 128) == 0   # one task does the whole device build
+    size = L.rtk_get_build_size(b)
+    assert size > 10000 * 48
+    small = np.zeros(1024, np.uint8)
+    assert not L.rtk_finish_build_to(b, small.ctypes.data, small.size)   # too small: NULL, build stays alive
+    buf = oracle._aligned_bytes(size)
+    s = L.rtk_finish_build_to(b, buf.ctypes.data, size)
+    assert s == buf.ctypes.data
+    assert oracle.validate_blob(oracle.Blob(buf))[0] == 0
+    rays = synth.rays_config1(1024)
+    hits, mask = api.trace_rays(s, rays)
+    ohits, omask = oracle.trace(oracle.Blob(buf), rays)
+    assert (mask == omask).all() and (hits["triangle_index"][mask] == ohits["triangle_index"][omask]).all()
+    L.rtk_amd_forget_scene(s)
+
+
+@pytest.mark.slow
+def test_config2_device_build_vs_golden_and_oracle(api, oracle, golden_dir):
+    tris = synth.scene_for_config(2)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    assert ds.info()["num_triangles"] == 1_000_000
+    blob = _as_blob(oracle, ds.export_blob())
+    rc, counts = oracle.validate_blob(blob)
+    assert rc == 0 and counts["tris"] == 1_000_000
+    g2 = load_golden(golden_dir, "cfg2_sample.npz")
+    r2 = np.concatenate([synth.rays_pinhole(first=int(i), count=1) for i in g2["ray_index"]])
+    hits, mask, _ = ds.trace(r2)
+    compare_hits_struct(hits, mask, g2, "lbvh cfg2 sample")
+    g3 = load_golden(golden_dir, "cfg3_sample.npz")
+    hits, mask, _ = ds.trace(synth.rays_incoherent(4096))
+    compare_hits_struct(hits, mask, g3, "lbvh cfg3 sample")
+    sel = np.arange(0, 4096 * 4096, 61)
+    rays = np.concatenate([synth.rays_pinhole(first=int(a), count=1) for a in sel[:4096]] +
+                          [synth.rays_incoherent(1 << 18)])
+    _same_as_oracle(oracle, blob, ds, rays, "lbvh 1M vs oracle on exported blob")
