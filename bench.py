@@ -153,6 +153,20 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM traffic of the same launch from the committed rocprofv3 PMC summary (separate passes; see
+    # scripts/profile_round1.sh + scripts/summarize_profile.py), newest round first
+    traffic, traffic_src = None, None
+    import glob
+    tag = "coherent" if args.workload == "coherent" else "incoherent"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_lbvh_pmc.json" % tag)), reverse=True):
+        try:
+            pj = json.load(open(f))
+            if args.bvh == "device" and "hbm_traffic_bytes_per_launch" in pj:
+                traffic, traffic_src = float(pj["hbm_traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
+                break
+        except Exception:
+            pass
+
     total_rays = n * world * args.steps
     mrays = total_rays / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
@@ -175,7 +189,9 @@ def main():
                    "gather": bool(world > 1 and not args.no_gather), "launch": "static" if args.static else "persistent",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
                      "kernel": "rtk_trace_kernel<0,false>", "kernel_ms": round(k_ms, 4),
                      "algorithmic_bytes_per_ray": round(alg_bytes / n, 1),
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
