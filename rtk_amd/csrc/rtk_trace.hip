@@ -45,6 +45,41 @@ __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : 
 __device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// All seven 16-B pieces of a node are requested back to back and waited for once. Left to
+// itself hipcc serialises them (load, wait, reuse the registers, load ...) to save VGPRs,
+// which turns one memory round trip per node into four. SGPR base + 32-bit VGPR offsets.
+__device__ __forceinline__ void load_node(const char *base, uint32_t a_nx, uint32_t a_fx, uint32_t a_ny, uint32_t a_fy,
+	uint32_t a_nz, uint32_t a_fz, uint32_t a_node, f32x4 &nx, f32x4 &fx, f32x4 &ny, f32x4 &fy, f32x4 &nz, f32x4 &fz, u32x4 &ch)
+{
+	asm volatile(
+		"global_load_dwordx4 %0, %7, %14\n\t"
+		"global_load_dwordx4 %1, %8, %14\n\t"
+		"global_load_dwordx4 %2, %9, %14\n\t"
+		"global_load_dwordx4 %3, %10, %14\n\t"
+		"global_load_dwordx4 %4, %11, %14\n\t"
+		"global_load_dwordx4 %5, %12, %14\n\t"
+		"global_load_dwordx4 %6, %13, %14 offset:96\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(nx), "=&v"(fx), "=&v"(ny), "=&v"(fy), "=&v"(nz), "=&v"(fz), "=&v"(ch)
+		: "v"(a_nx), "v"(a_fx), "v"(a_ny), "v"(a_fy), "v"(a_nz), "v"(a_fz), "v"(a_node), "s"(base)
+		: "memory");
+}
+
+__device__ __forceinline__ void load_tri(const char *base, uint32_t a_tri, f32x4 &A, f32x4 &B, f32x4 &C)
+{
+	asm volatile(
+		"global_load_dwordx4 %0, %3, %4\n\t"
+		"global_load_dwordx4 %1, %3, %4 offset:16\n\t"
+		"global_load_dwordx4 %2, %3, %4 offset:32\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(A), "=&v"(B), "=&v"(C)
+		: "v"(a_tri), "s"(base)
+		: "memory");
+}
+
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb)
 {
 	const bool s = kb < ka;
@@ -104,6 +139,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 	uint32_t top = RTK_REF_NONE;
 	uint32_t sp = 0;
 	uint32_t c_nodes = 0, c_leaves = 0, c_tris = 0, c_spills = 0;
+	// A ray is "special" if its slab products can be NaN (0*inf) or its inputs are not finite;
+	// only then does the SSE operand order of min/max matter (see node step).
+	bool special = false;
+	bool wave_fast = true;   // wave-uniform: no active lane is special
 
 	for (;;) {
 		// ---------------------------------------------------------------- refill
@@ -157,6 +196,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					onx = sx * 16u;        ofx = 16u - onx;
 					ony = 32u + sy * 16u;  ofy = 80u - ony;
 					onz = 64u + sz * 16u;  ofz = 144u - onz;
+					special = !(isfinite(rdx) && isfinite(rdy) && isfinite(rdz) && rdx != 0.0f && rdy != 0.0f && rdz != 0.0f &&
+						isfinite(ox) && isfinite(oy) && isfinite(oz) && tmin_ray == tmin_ray && tmax_ray == tmax_ray);
 					best_t = tmax_ray; best_u = 0.0f; best_v = 0.0f; best_prim = RTK_PRIM_NONE;
 					top = 0u;  // root node
 					sp = 0u;
@@ -164,6 +205,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 				}
 				w_next += take;
 			}
+			wave_fast = __ballot(active && special) == 0ull;
 			if (__ballot(active) == 0ull) {
 				if (pool_empty && w_next >= w_end) break;
 				continue;
@@ -172,29 +214,42 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 
 		// ---------------------------------------------------------------- inner nodes
 		while (active && (int32_t)top >= 0) {
-			const char *nb = nodes + (size_t)top * 128u;
-			const float4 nx = ld_f4(nb + onx), fx = ld_f4(nb + ofx);
-			const float4 ny = ld_f4(nb + ony), fy = ld_f4(nb + ofy);
-			const float4 nz = ld_f4(nb + onz), fz = ld_f4(nb + ofz);
-			const uint4 ch = ld_u4(nb + 96);
+			const uint32_t a_node = top << 7;
+			f32x4 nx, fx, ny, fy, nz, fz;
+			u32x4 ch;
+			load_node(nodes, a_node + onx, a_node + ofx, a_node + ony, a_node + ofy, a_node + onz, a_node + ofz, a_node,
+				nx, fx, ny, fy, nz, fz, ch);
 			if (COUNT) c_nodes++;
-			const float nxa[4] = { nx.x, nx.y, nx.z, nx.w }, fxa[4] = { fx.x, fx.y, fx.z, fx.w };
-			const float nya[4] = { ny.x, ny.y, ny.z, ny.w }, fya[4] = { fy.x, fy.y, fy.z, fy.w };
-			const float nza[4] = { nz.x, nz.y, nz.z, nz.w }, fza[4] = { fz.x, fz.y, fz.z, fz.w };
 			uint32_t ref[4] = { ch.x, ch.y, ch.z, ch.w };
 			float key[4];
 			uint32_t nhit = 0;
+			if (wave_fast) {
+				// No NaN can arise for these rays, so min/max are order-free: v_max3/v_min3.
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				// rtk.c:458-465: (bound - origin) * rcp_dir, then the folded interval test
-				const float ax = (nxa[i] - ox) * rdx, bx = (fxa[i] - ox) * rdx;
-				const float ay = (nya[i] - oy) * rdy, by = (fya[i] - oy) * rdy;
-				const float az = (nza[i] - oz) * rdz, bz = (fza[i] - oz) * rdz;
-				const float tn = sse_max(sse_max(ax, ay), sse_max(az, tmin_ray));
-				const float tf = sse_min(sse_min(bx, by), sse_min(bz, best_t));
-				const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
-				key[i] = h ? tn : __builtin_inff();
-				nhit += h ? 1u : 0u;
+				for (int i = 0; i < 4; i++) {
+					const float ax = (nx[i] - ox) * rdx, bx = (fx[i] - ox) * rdx;
+					const float ay = (ny[i] - oy) * rdy, by = (fy[i] - oy) * rdy;
+					const float az = (nz[i] - oz) * rdz, bz = (fz[i] - oz) * rdz;
+					const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin_ray);
+					const float tf = fminf(fminf(fminf(bx, by), bz), best_t);
+					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
+					key[i] = h ? tn : __builtin_inff();
+					nhit += h ? 1u : 0u;
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					// rtk.c:458-465: (bound - origin) * rcp_dir, then the folded interval test with
+					// _mm_max_ps/_mm_min_ps operand order (decides what a NaN from 0*inf does)
+					const float ax = (nx[i] - ox) * rdx, bx = (fx[i] - ox) * rdx;
+					const float ay = (ny[i] - oy) * rdy, by = (fy[i] - oy) * rdy;
+					const float az = (nz[i] - oz) * rdz, bz = (fz[i] - oz) * rdz;
+					const float tn = sse_max(sse_max(ax, ay), sse_max(az, tmin_ray));
+					const float tf = sse_min(sse_min(bx, by), sse_min(bz, best_t));
+					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
+					key[i] = h ? tn : __builtin_inff();
+					nhit += h ? 1u : 0u;
+				}
 			}
 			// nearest first (rtk.c:496-517 orders by entry distance)
 			cswap(key[0], ref[0], key[1], ref[1]);
@@ -242,8 +297,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			float sn_t = best_t, sn_u = best_u, sn_v = best_v;
 			uint32_t sn_prim = best_prim;
 			while (i < n) {
-				const char *tb = tris + (size_t)(slot0 + i) * 48u;
-				const float4 A = ld_f4(tb), B = ld_f4(tb + 16), C = ld_f4(tb + 32);
+				f32x4 A, B, C;
+				load_tri(tris, (slot0 + i) * 48u, A, B, C);
 				if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
 				if ((i & 3u) == 0u) {
 					if (redo) { force = true; redo = false; }
@@ -390,6 +445,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
 	if (!ds || (!d_rays && n) || ((any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
+	// the kernel addresses nodes and triangles as SGPR base + 32-bit byte offset
+	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * 48u > 0xffffff00ull) {
+		rtk_set_error("rtk_dev_trace: scene exceeds 4 GiB of nodes or triangles (%u nodes, %u triangles)", ds->view.num_nodes, ds->view.num_tris);
+		return RTK_AMD_ERR_UNSUPPORTED;
+	}
 
 	TraceParams p = {};
 	p.sc = ds->view;
