@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-tiling", action="store_true")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--node-exit", type=int, default=0)
     ap.add_argument("--frame", type=int, default=4096)
     args = ap.parse_args()
 
@@ -95,11 +96,11 @@ def main():
     if args.workload == "coherent":
         rays = synth.rays_pinhole(W, H, jitter=synth.frame_jitter(rank))
         opts = api.make_opts(image=None if args.no_tiling else (W, H), static=args.static,
-                             refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu)
+                             refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit)
         workload = "config2: 1M-tri soup (seed 1, spread 0.02), %dx%d coherent pinhole primary rays" % (W, H)
     else:
         rays = synth.rays_incoherent(n, first=rank * n)
-        opts = api.make_opts(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu)
+        opts = api.make_opts(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit)
         workload = "config3: 1M-tri soup, %d incoherent rays" % n
     d_rays = api.to_device(rays)
     d_rec = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device="cuda")

@@ -79,6 +79,7 @@ typedef struct rtk_trace_opts {
 	uint32_t image_height;     /* row-major image; lanes are mapped to 8x8 pixel tiles  */
 	uint32_t refill_min;       /* 0 = default; idle lanes needed before a wave refills  */
 	uint32_t blocks_per_cu;    /* 0 = default; persistent grid size                     */
+	uint32_t node_exit;        /* 0 = default; see DESIGN.md 3.1 (divergence control)   */
 } rtk_trace_opts;
 #define RTK_TRACE_STATIC   1u   /* one fixed ray per lane, no persistent refill (A/B only) */
 

@@ -35,7 +35,8 @@ class SceneInfo(C.Structure):
 
 class TraceOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("image_width", C.c_uint32),
-                ("image_height", C.c_uint32), ("refill_min", C.c_uint32), ("blocks_per_cu", C.c_uint32)]
+                ("image_height", C.c_uint32), ("refill_min", C.c_uint32), ("blocks_per_cu", C.c_uint32),
+                ("node_exit", C.c_uint32)]
 
 
 class TraceCounters(C.Structure):
@@ -138,7 +139,7 @@ def to_device(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0):
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = RTK_TRACE_STATIC if static else 0
@@ -146,6 +147,7 @@ def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0):
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min
     o.blocks_per_cu = blocks_per_cu
+    o.node_exit = node_exit
     return o
 
 

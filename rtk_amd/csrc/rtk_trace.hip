@@ -36,6 +36,7 @@ struct TraceParams {
 	uint32_t image_w, image_h;     // 0 = no tiling
 	uint32_t refill_min;
 	uint32_t dynamic;
+	uint32_t node_exit;            // leave the node loop when fewer lanes than this still need node steps and a leaf is waiting
 };
 
 // _mm_min_ps/_mm_max_ps semantics (second operand when the compare is false, NaN included)
@@ -213,7 +214,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 		}
 
 		// ---------------------------------------------------------------- inner nodes
-		while (active && (int32_t)top >= 0) {
+		for (;;) {
+			// Lanes that reached a leaf wait here for the others. When only a few lanes are
+			// still descending and leaves are waiting, go and do the leaves first.
+			const bool want_node = active && (int32_t)top >= 0;
+			const unsigned long long m_node = __ballot(want_node);
+			if (m_node == 0ull) break;
+			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
+			if (!want_node) continue;
 			const uint32_t a_node = top << 7;
 			f32x4 nx, fx, ny, fy, nz, fz;
 			u32x4 ch;
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 		// known up front; a zero inside a full group is rare, so the group is simply
 		// redone from a snapshot of the best hit. This keeps t/u/v bit-identical to
 		// rtk.c traversing the same leaves.
-		if (active && top != RTK_REF_NONE) {
+		if (active && top != RTK_REF_NONE && (int32_t)top < 0) {
 			const uint32_t slot0 = top & 0x7fffffffu;
 			if (COUNT) c_leaves++;
 			uint32_t i = 0, n = 1;
@@ -458,7 +466,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.occluded = d_occluded;
 	p.n = n;
 	p.dynamic = 1;
-	p.refill_min = 64;
+	// Defaults from sweeps on MI355X (gpurun_out/sweep_opts*.log): leave the node
+	// loop once fewer than 24 lanes still descend; image-shaped (tiled, coherent) batches refill a
+	// wave only when it is empty, everything else as soon as 8 lanes are idle.
+	p.refill_min = 8;
+	p.node_exit = 24;
 	uint32_t blocks_per_cu = 0;
 	if (opts && opts->struct_size >= 16) {
 		if (opts->flags & RTK_TRACE_STATIC) p.dynamic = 0;
@@ -466,11 +478,13 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			(opts->image_width % 8u) == 0 && (opts->image_height % 8u) == 0) {
 			p.image_w = opts->image_width;
 			p.image_h = opts->image_height;
+			p.refill_min = 64;
 		}
 		if (opts->struct_size >= 24) {
 			if (opts->refill_min) p.refill_min = opts->refill_min > 64 ? 64 : opts->refill_min;
 			blocks_per_cu = opts->blocks_per_cu;
 		}
+		if (opts->struct_size >= 28 && opts->node_exit) p.node_exit = opts->node_exit > 64 ? 64 : opts->node_exit;
 	}
 
 	static int occ[2][2] = { { 0, 0 }, { 0, 0 } };

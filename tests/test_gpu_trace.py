@@ -78,7 +78,7 @@ def test_edge_cases_vs_golden(api, oracle, golden_dir):
     compare_hits_struct(hits2, mask2, g, "gpu/edge single leaf")
 
 
-@pytest.mark.parametrize("mode", ["static", "refill8", "tiled"])
+@pytest.mark.parametrize("mode", ["static", "refill8", "tiled", "node_exit16", "node_exit64_refill8", "node_exit64_static"])
 def test_launch_modes_agree(api, scene1, mode):
     _, ds = scene1
     rays = synth.rays_config1(65536)
@@ -87,6 +87,12 @@ def test_launch_modes_agree(api, scene1, mode):
         opts = api.make_opts(static=True)
     elif mode == "refill8":
         opts = api.make_opts(refill_min=8, blocks_per_cu=1)
+    elif mode == "node_exit16":
+        opts = api.make_opts(node_exit=16)
+    elif mode == "node_exit64_refill8":
+        opts = api.make_opts(node_exit=64, refill_min=8)
+    elif mode == "node_exit64_static":
+        opts = api.make_opts(node_exit=64, static=True)
     else:
         opts = api.make_opts(image=(256, 256))
     other = ds.trace(rays, opts=opts, full=False)
