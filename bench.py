@@ -7,13 +7,20 @@
 A "step" is one pass of the hot path over one batch: every rank traces its own 4096x4096
 frame (2^24 rays; N=1 is BASELINE.json configs[1], N>1 is configs[3]: frame r on rank r,
 BVH replicated) and, for N>1, the 16-byte hit records are gathered onto rank 0 over RCCL.
-Rays, BVH and hit records are resident in HBM for the whole timed region.
+Rays, BVH and hit records are resident in HBM for the whole timed region. The BVH is
+built on the GPU by the product path (rtk_dev_scene_build) before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): whole-job Mrays/s, plus
   roofline:     algorithmic bytes of the traversal kernel / its measured duration vs 8 TB/s
-  cpu_baseline: the CPU oracle (a port of rtk.c's trace path) timed on this host's cores.
+  cpu_baseline: the CPU oracle (a port of rtk.c's trace path) timed on this host's cores,
+                with the parity of the timed GPU result against it.
+
+Other BASELINE.json configs (parity-test cases, not the headline line):
+  --workload incoherent   config 3: 2^24 random rays on the same scene
+  --workload shadow       config 5: 10M-triangle scene, GPU build timed, 2^24 any-hit shadow rays
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -38,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="coherent", choices=["coherent", "incoherent"])
+    ap.add_argument("--workload", default="coherent", choices=["coherent", "incoherent", "shadow"])
     ap.add_argument("--bvh", default="device", choices=["device", "oracle-blob"],
                     help="device = GPU LBVH build (product path); oracle-blob = upload a blob built by the CPU oracle (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,7 +77,8 @@ def main():
 
     W = H = args.frame
     n = W * H
-    cfg = synth.CONFIGS[2]
+    shadow = args.workload == "shadow"
+    cfg = synth.CONFIGS[5 if shadow else 2]
 
     # ---- scene: replicated on every rank -------------------------------------------------
     t0 = time.time()
@@ -93,28 +101,42 @@ def main():
         log("scene: %d tris generated in %.2fs, bvh (%s) in %.2fs: %s" % (cfg["num_tris"], t_gen, bvh_kind, t_build, info))
 
     # ---- rays: frame `rank` of config 4 (frame 0 == config 2) ------------------------------
+    common = dict(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit)
     if args.workload == "coherent":
         rays = synth.rays_pinhole(W, H, jitter=synth.frame_jitter(rank))
-        opts = api.make_opts(image=None if args.no_tiling else (W, H), static=args.static,
-                             refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit)
+        opts = api.make_opts(image=None if args.no_tiling else (W, H), **common)
         workload = "config2: 1M-tri soup (seed 1, spread 0.02), %dx%d coherent pinhole primary rays" % (W, H)
-    else:
+        metric = "Mrays/sec (primary, closest-hit) on 1M-tri scene"
+    elif args.workload == "incoherent":
         rays = synth.rays_incoherent(n, first=rank * n)
-        opts = api.make_opts(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit)
+        opts = api.make_opts(**common)
         workload = "config3: 1M-tri soup, %d incoherent rays" % n
+        metric = "Mrays/sec (incoherent, closest-hit) on 1M-tri scene"
+    else:
+        rays = synth.rays_shadow(n, first=rank * n)
+        opts = api.make_opts(**common)
+        workload = "config5: 10M-tri soup (spread 0.01), GPU LBVH build + %d any-hit shadow rays" % n
+        metric = "Mrays/sec (any-hit shadow) on 10M-tri scene"
     d_rays = api.to_device(rays)
-    d_rec = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device="cuda")
-    sizes = [n * HIT_BYTES] * world
+    out_bytes = 1 if shadow else HIT_BYTES
+    d_out = torch.empty(n * out_bytes, dtype=torch.uint8, device="cuda")
+    sizes = [n * out_bytes] * world
+
+    def trace():
+        if shadow:
+            ds.trace_any_device(d_rays, n, d_out, opts)
+        else:
+            ds.trace_device(d_rays, n, d_out, opts)
 
     def step():
-        ds.trace_device(d_rays, n, d_rec, opts)
+        trace()
         if world > 1 and not args.no_gather:
-            return shard.gather_records(d_rec, sizes, dst=0)
-        return d_rec
+            return shard.gather_records(d_out, sizes, dst=0)
+        return d_out
 
     # ---- algorithmic bytes from the counting build (not timed) ----------------------------
-    _, ctr = ds.trace_counted(rays, opts)
-    alg_bytes = n * (RAY_BYTES + HIT_BYTES) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
+    _, ctr = ds.trace_any_counted(rays, opts) if shadow else ds.trace_counted(rays, opts)
+    alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
     torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -129,10 +151,10 @@ def main():
     t_start = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()                       # same stream the kernel is launched on
-        ds.trace_device(d_rays, n, d_rec, opts)
+        trace()
         ev[k][1].record()
         if world > 1 and not args.no_gather:
-            shard.gather_records(d_rec, sizes, dst=0)
+            shard.gather_records(d_out, sizes, dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -145,9 +167,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- sanity of the result that was timed ---------------------------------------------
-    rec = d_rec.cpu().numpy().view(HIT_RECORD_DTYPE)
-    hit_frac = float((rec["prim"] != 0xFFFFFFFF).mean())
+    # ---- the result that was timed ---------------------------------------------------------
+    if shadow:
+        occ = d_out.cpu().numpy().astype(bool)
+        hit_frac = float(occ.mean())
+    else:
+        rec = d_out.cpu().numpy().view(HIT_RECORD_DTYPE)
+        hit_frac = float((rec["prim"] != 0xFFFFFFFF).mean())
 
     if rank != 0:
         if world > 1:
@@ -155,11 +181,9 @@ def main():
         return
 
     # HBM traffic of the same launch from the committed rocprofv3 PMC summary (separate passes; see
-    # scripts/profile_round1.sh + scripts/summarize_profile.py), newest round first
+    # scripts/profile_round1.sh + scripts/summarize_profile.py), newest file first
     traffic, traffic_src = None, None
-    import glob
-    tag = "coherent" if args.workload == "coherent" else "incoherent"
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_lbvh_pmc.json" % tag)), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_lbvh_pmc.json" % args.workload)), reverse=True):
         try:
             pj = json.load(open(f))
             if args.bvh == "device" and "hbm_traffic_bytes_per_launch" in pj:
@@ -173,7 +197,7 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     out = {
-        "metric": "Mrays/sec (primary, closest-hit) on 1M-tri scene",
+        "metric": metric,
         "value": round(mrays, 2),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -186,14 +210,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "rays_per_gpu_per_step": n, "bvh": bvh_kind, "bvh_nodes": info["num_nodes"],
-                   "bvh_build_s": round(t_build, 3), "hit_fraction": round(hit_frac, 4),
+                   "bvh_build_s": round(t_build, 3), "bvh_build_ms_in_library": round(info["build_ms"], 2),
+                   "bvh_build_mtris_s": round(cfg["num_tris"] / max(info["build_ms"], 1e-9) / 1e3, 1) if info["build_ms"] else None,
+                   "hit_fraction": round(hit_frac, 4),
                    "gather": bool(world > 1 and not args.no_gather), "launch": "static" if args.static else "persistent",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "kernel": "rtk_trace_kernel<0,false>", "kernel_ms": round(k_ms, 4),
+                     "kernel": "rtk_trace_kernel<%d,false>" % (1 if shadow else 0), "kernel_ms": round(k_ms, 4),
                      "algorithmic_bytes_per_ray": round(alg_bytes / n, 1),
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
                                         "triangles": round(ctr["triangles"] / n, 2)},
@@ -225,23 +251,33 @@ def main():
         t0 = time.time()
         pyoracle.trace(oracle_blob, rays[probe_sel], threads=1)
         rate1 = len(probe_sel) / max(time.time() - t0, 1e-6)
-        # parity of the timed GPU result against the same CPU run (ids exact, t to 1e-5)
-        g = rec[sel]
-        gm = g["prim"] != 0xFFFFFFFF
-        mask_ok = bool((gm == omask).all())
-        both = gm & omask
-        id_mismatch = int((g["prim"][both] != ohits["triangle_index"][both]).sum()) + int((gm != omask).sum())
-        ids_ok = mask_ok and id_mismatch == 0
-        rel = float(np.max(np.abs(g["t"][both] - ohits["t"][both]) / np.abs(ohits["t"][both]))) if both.any() else 0.0
-        bit_exact = float(np.mean((g["t"][both] == ohits["t"][both]) & (g["u"][both] == ohits["u"][both]) &
-                                  (g["v"][both] == ohits["v"][both]))) if both.any() else 1.0
-        out["cpu_baseline"] = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                               "sample": "%d rays = every %d-th ray of the same batch, oracle SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"
-                                         % (sample, stride, t_cpu_build, threads, rate1 / 1e6),
-                               "host_cpus": os.cpu_count(),
-                               "parity_vs_gpu": {"rays": sample, "ids_exact": ids_ok, "id_mismatches": id_mismatch,
-                                                 "max_rel_t": rel, "tuv_bit_exact_fraction": bit_exact,
-                                                 "same_bvh": bool(args.bvh == "oracle-blob")}}
+
+        def parity(oh, om):
+            if shadow:
+                return {"rays": sample, "occluded_flag_mismatches": int((occ[sel] != om).sum())}
+            g = rec[sel]
+            gm = g["prim"] != 0xFFFFFFFF
+            both = gm & om
+            mism = int((g["prim"][both] != oh["triangle_index"][both]).sum()) + int((gm != om).sum())
+            rel = float(np.max(np.abs(g["t"][both] - oh["t"][both]) / np.abs(oh["t"][both]))) if both.any() else 0.0
+            exact = float(np.mean((g["t"][both] == oh["t"][both]) & (g["u"][both] == oh["u"][both]) &
+                                  (g["v"][both] == oh["v"][both]))) if both.any() else 1.0
+            return {"rays": sample, "ids_exact": mism == 0, "id_mismatches": mism, "max_rel_t": rel, "tuv_bit_exact_fraction": exact}
+
+        base = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": "%d rays = every %d-th ray of the same batch, closest-hit on the oracle's SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"
+                          % (sample, stride, t_cpu_build, threads, rate1 / 1e6),
+                "host_cpus": os.cpu_count()}
+        # (1) the CPU's own BVH: another valid BVH of the same triangles (near-ties may resolve differently)
+        base["parity_vs_gpu_oracle_bvh"] = parity(ohits, omask)
+        # (2) the SAME BVH: the oracle traverses the blob exported from the GPU-built scene -> bit-exact
+        if args.bvh == "device":
+            exported = pyoracle.Blob(ds.export_blob())
+            eh, em = pyoracle.trace(exported, sample_rays, threads=threads)
+            base["parity_vs_gpu_same_bvh"] = parity(eh, em)
+        else:
+            base["parity_vs_gpu_same_bvh"] = base["parity_vs_gpu_oracle_bvh"]
+        out["cpu_baseline"] = base
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

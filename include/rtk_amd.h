@@ -69,6 +69,7 @@ typedef struct rtk_dev_scene_info {
 	uint64_t total_device_bytes;
 	uint32_t max_depth;        /* deepest 4-wide node level (root = 1) */
 	uint32_t stack_entries;    /* traversal stack entries a ray can need */
+	double build_ms;           /* wall time inside rtk_dev_scene_build (0 for uploads) */
 } rtk_dev_scene_info;
 
 /* Trace options; pass NULL for defaults. */
@@ -113,6 +114,9 @@ int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record *d_records
 /* Same result as rtk_dev_trace_rays, plus visit counts. Synchronous; not for timing. */
 int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_trace_counters *out);
+
+int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	uint8_t *d_occluded, const rtk_trace_opts *opts, rtk_trace_counters *out);
 
 /* -- host-pointer convenience (PCIe-inclusive, synchronous) --
  * Closest hits of n rays against a scene blob. hits[i] is written where the ray hit

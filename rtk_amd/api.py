@@ -27,10 +27,10 @@ class RtkError(RuntimeError):
 class SceneInfo(C.Structure):
     _fields_ = [("num_triangles", C.c_uint64), ("num_meshes", C.c_uint64), ("num_nodes", C.c_uint64),
                 ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("total_device_bytes", C.c_uint64),
-                ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32)]
+                ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32), ("build_ms", C.c_double)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        return {k: (float(getattr(self, k)) if k == "build_ms" else int(getattr(self, k))) for k, _ in self._fields_}
 
 
 class TraceOpts(C.Structure):
@@ -54,7 +54,7 @@ RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_
                      "rtk_dev_scene_upload", "rtk_dev_scene_build", "rtk_dev_scene_free", "rtk_dev_scene_get_info",
                      "rtk_dev_scene_mesh_base", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
                      "rtk_dev_trace_rays", "rtk_dev_trace_rays_any", "rtk_dev_expand_hits",
-                     "rtk_dev_trace_rays_counted", "rtk_trace_rays", "rtk_amd_forget_scene"]
+                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_trace_rays", "rtk_amd_forget_scene"]
 
 _lib = None
 
@@ -90,6 +90,8 @@ def lib():
     L.rtk_dev_expand_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rtk_dev_trace_rays_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts),
                                              C.POINTER(TraceCounters)]
+    L.rtk_dev_trace_rays_any_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts),
+                                                 C.POINTER(TraceCounters)]
     L.rtk_trace_rays.restype = C.c_size_t
     L.rtk_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.rtk_amd_forget_scene.argtypes = [C.c_void_p]
@@ -262,6 +264,19 @@ class DeviceScene:
         n = rays.shape[0]
         d_rays = to_device(rays)
         return self.trace_any_device(d_rays, n, opts=opts).cpu().numpy().astype(bool)
+
+    def trace_any_counted(self, rays, opts=None):
+        torch = _torch()
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        d_rays = to_device(rays)
+        d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctr = TraceCounters()
+        torch.cuda.synchronize()
+        _check(lib().rtk_dev_trace_rays_any_counted(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_occ.data_ptr()),
+                                                    C.byref(opts) if opts is not None else None, C.byref(ctr)),
+               "rtk_dev_trace_rays_any_counted")
+        return d_occ.cpu().numpy().astype(bool), ctr.as_dict()
 
     def trace_counted(self, rays, opts=None):
         torch = _torch()

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 
 void rtk_cache_adopt(const rtk_scene *scene, rtk_dev_scene *ds);
@@ -646,6 +647,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	if (n64 >= 0x3ffffff0ull) { rtk_set_error("rtk_dev_scene_build: more than 2^30 triangles"); return nullptr; }
 	const uint32_t n = (uint32_t)n64;
 	if (desc->log_fn) desc->log_fn(desc->log_user, nullptr, "rtk_amd: device LBVH build");
+	const auto t_begin = std::chrono::steady_clock::now();
 
 	int device = 0;
 	hipDeviceProp_t prop;
@@ -837,6 +839,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	ds->view.num_prims = n;
 	ds->max_depth = depth;
 	ds->stack_entries = 3u * depth + 1u;
+	ds->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 	return ds;
 }
 

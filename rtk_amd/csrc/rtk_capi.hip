@@ -72,6 +72,7 @@ extern "C" int rtk_dev_scene_get_info(const rtk_dev_scene *ds, rtk_dev_scene_inf
 	info->total_device_bytes = ds->total_bytes;
 	info->max_depth = ds->max_depth;
 	info->stack_entries = ds->stack_entries;
+	info->build_ms = ds->build_ms;
 	return RTK_AMD_OK;
 }
 
@@ -101,6 +102,13 @@ extern "C" int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray
 {
 	if (!out) { rtk_set_error("rtk_dev_trace_rays_counted: NULL counters"); return RTK_AMD_ERR_BAD_ARG; }
 	return rtk_launch_trace(ds, d_rays, n, d_hits, nullptr, opts, nullptr, false, out);
+}
+
+extern "C" int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	uint8_t *d_occluded, const rtk_trace_opts *opts, rtk_trace_counters *out)
+{
+	if (!out) { rtk_set_error("rtk_dev_trace_rays_any_counted: NULL counters"); return RTK_AMD_ERR_BAD_ARG; }
+	return rtk_launch_trace(ds, d_rays, n, nullptr, d_occluded, opts, nullptr, true, out);
 }
 
 extern "C" int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n,

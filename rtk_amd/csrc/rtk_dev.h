@@ -57,6 +57,7 @@ struct rtk_dev_scene {
 	uint32_t max_depth = 0;
 	uint32_t stack_entries = 0;
 	uint64_t total_bytes = 0;
+	double build_ms = 0.0;
 	// owned device allocations
 	std::vector<void *> allocs;
 	// per-scene scratch for launches (lazily sized)

@@ -173,3 +173,26 @@ def test_config2_device_build_vs_golden_and_oracle(api, oracle, golden_dir):
     rays = np.concatenate([synth.rays_pinhole(first=int(a), count=1) for a in sel[:4096]] +
                           [synth.rays_incoherent(1 << 18)])
     _same_as_oracle(oracle, blob, ds, rays, "lbvh 1M vs oracle on exported blob")
+
+
+@pytest.mark.slow
+def test_config5_device_build_any_hit_vs_golden(api, golden_dir):
+    """10M-triangle scene built on the GPU; the 1024 golden shadow rays (made by the real reference's
+    leaf chain over all 10M triangles): occluded flag == reference hit boolean, closest hit == reference."""
+    tris = synth.scene_for_config(5)
+    g = load_golden(golden_dir, "cfg5_sample.npz")
+    from tests.util import sha
+    assert sha(tris) == str(g["scene_sha256"])
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    info = ds.info()
+    assert info["num_triangles"] == 10_000_000 and info["build_ms"] > 0
+    rays = synth.rays_shadow(1024)
+    assert sha(rays) == str(g["rays_sha256"])
+    occ = ds.trace_any(rays)
+    assert (occ == g["hit_mask"].astype(bool)).all()
+    hits, mask, _ = ds.trace(rays)
+    compare_hits_struct(hits, mask, g, "lbvh cfg5 sample")
+    # a larger batch: any-hit flag equals the closest-hit boolean
+    big = synth.rays_shadow(1 << 20)
+    rec = ds.trace(big, full=False)
+    assert (ds.trace_any(big) == (rec["prim"] != 0xFFFFFFFF)).all()
