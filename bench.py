@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave hit records on their GPU")
     ap.add_argument("--static", action="store_true", help="A/B: one fixed ray per lane instead of persistent refill")
     ap.add_argument("--no-tiling", action="store_true")
+    ap.add_argument("--no-packet", action="store_true", help="A/B: image-shaped batch on the per-lane kernel")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--node-exit", type=int, default=0)
@@ -101,7 +102,8 @@ def main():
         log("scene: %d tris generated in %.2fs, bvh (%s) in %.2fs: %s" % (cfg["num_tris"], t_gen, bvh_kind, t_build, info))
 
     # ---- rays: frame `rank` of config 4 (frame 0 == config 2) ------------------------------
-    common = dict(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit)
+    common = dict(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit,
+                  no_packet=args.no_packet)
     if args.workload == "coherent":
         rays = synth.rays_pinhole(W, H, jitter=synth.frame_jitter(rank))
         opts = api.make_opts(image=None if args.no_tiling else (W, H), **common)
@@ -219,10 +221,13 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "kernel": "rtk_trace_kernel<%d,false>" % (1 if shadow else 0), "kernel_ms": round(k_ms, 4),
+                     "kernel": ("rtk_trace_packet_kernel<false>" if (args.workload == "coherent" and not args.no_tiling and not args.no_packet)
+                                else "rtk_trace_kernel<%d,false>" % (1 if shadow else 0)), "kernel_ms": round(k_ms, 4),
                      "algorithmic_bytes_per_ray": round(alg_bytes / n, 1),
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
                                         "triangles": round(ctr["triangles"] / n, 2)},
+                     "wave_steps_per_64_rays": {"nodes": round(ctr["wave_node_steps"] * 64.0 / n, 1),
+                                                "triangles": round(ctr["wave_triangle_steps"] * 64.0 / n, 1)},
                      "kernel_mrays_s": round(n / (k_ms * 1e-3) / 1e6, 1)},
     }
 

@@ -82,7 +82,8 @@ typedef struct rtk_trace_opts {
 	uint32_t blocks_per_cu;    /* 0 = default; persistent grid size                     */
 	uint32_t node_exit;        /* 0 = default; see DESIGN.md 3.1 (divergence control)   */
 } rtk_trace_opts;
-#define RTK_TRACE_STATIC   1u   /* one fixed ray per lane, no persistent refill (A/B only) */
+#define RTK_TRACE_STATIC    1u   /* one fixed ray per lane, no persistent refill (A/B only) */
+#define RTK_TRACE_NO_PACKET 2u   /* image-shaped batch, but use the per-lane kernel (A/B only) */
 
 /* Visit counters of the counting build (algorithmic-bytes model). */
 typedef struct rtk_trace_counters {
@@ -92,6 +93,9 @@ typedef struct rtk_trace_counters {
 	uint64_t triangles;        /* 48 B triangle records fetched       */
 	uint64_t hits;
 	uint64_t stack_spills;     /* pushes that went past the LDS stack */
+	uint64_t wave_node_steps;      /* wave-level node-loop trips (divergence diagnostics) */
+	uint64_t wave_triangle_steps;  /* wave-level triangle-loop trips */
+	uint64_t wave_rays;            /* reserved */
 } rtk_trace_counters;
 
 /* -- scenes -- */

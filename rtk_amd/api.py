@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librtk_amd.so")
 
 RTK_TRACE_STATIC = 1
+RTK_TRACE_NO_PACKET = 2
 
 
 class RtkError(RuntimeError):
@@ -41,7 +42,8 @@ class TraceOpts(C.Structure):
 
 class TraceCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("leaves", C.c_uint64),
-                ("triangles", C.c_uint64), ("hits", C.c_uint64), ("stack_spills", C.c_uint64)]
+                ("triangles", C.c_uint64), ("hits", C.c_uint64), ("stack_spills", C.c_uint64),
+                ("wave_node_steps", C.c_uint64), ("wave_triangle_steps", C.c_uint64), ("wave_rays", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -141,10 +143,10 @@ def to_device(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0):
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
-    o.flags = RTK_TRACE_STATIC if static else 0
+    o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0)
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

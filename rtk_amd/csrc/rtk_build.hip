@@ -714,7 +714,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 
 	BuildParams bp;
 	bp.cost_tri = env_float("RTK_AMD_SAH_CT", 1.0f);
-	bp.cost_node = env_float("RTK_AMD_SAH_CN", 1.0f);
+	bp.cost_node = env_float("RTK_AMD_SAH_CN", 0.5f);   // sweeps on MI355X: small leaves win (gpurun_out/sweep_sah2.log)
 	bp.max_leaf = (uint32_t)env_float("RTK_AMD_MAX_LEAF", 8.0f);
 	if (bp.max_leaf < 1) bp.max_leaf = 1;
 	if (bp.max_leaf > 63) bp.max_leaf = 63;     // 6-bit count in the blob's leaf header (rtk.c:188)
@@ -825,7 +825,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
 	if (!d_nodes) return fail("out of device memory");
 	if (hipMemcpy(d_nodes, d_nodes_tmp.p, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice) != hipSuccess) return fail("copy");
-	if (hipMalloc(&ds->d_counter, 8 * sizeof(unsigned long long)) != hipSuccess) return fail("out of device memory");
+	if (hipMalloc(&ds->d_counter, 16 * sizeof(unsigned long long)) != hipSuccess) return fail("out of device memory");
 	if (hipDeviceSynchronize() != hipSuccess) return fail("sync");
 
 	ds->view.nodes = d_nodes;

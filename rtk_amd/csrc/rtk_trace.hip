@@ -14,34 +14,10 @@
 // order in tri_test() is normative (sign of u,v,w decides hit/miss); see SURVEY.md
 // section 0. Divisions are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 #include "rtk_dev.h"
+#include "rtk_trace_shared.h"
 
 #include <math.h>
 #include <stdio.h>
-
-#define LDS_STACK 16           // entries per lane held in LDS
-#define WAVES_PER_BLOCK 4
-#define BLOCK_THREADS (64 * WAVES_PER_BLOCK)
-#define RAY_CHUNK 64           // rays taken from the global pool per atomic
-
-struct TraceParams {
-	DevSceneView sc;
-	const rtk_ray *rays;
-	rtk_hit_record *hits;
-	uint8_t *occluded;
-	unsigned long long *counter;   // [0] pool head, [1..6] visit counters
-	uint2 *spill;
-	unsigned long long n;
-	uint32_t spill_stride;         // lanes in the launch
-	uint32_t spill_cap;            // entries per lane in spill
-	uint32_t image_w, image_h;     // 0 = no tiling
-	uint32_t refill_min;
-	uint32_t dynamic;
-	uint32_t node_exit;            // leave the node loop when fewer lanes than this still need node steps and a leaf is waiting
-};
-
-// _mm_min_ps/_mm_max_ps semantics (second operand when the compare is false, NaN included)
-__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
-__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
 
 __device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -89,20 +65,6 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 	ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
-// Row-major image -> 8x8 pixel tiles, so that the 64 lanes of a wave share BVH nodes.
-__device__ __forceinline__ unsigned long long map_index(unsigned long long i, uint32_t w, uint32_t h)
-{
-	if (w == 0) return i;
-	const unsigned long long tile = i >> 6;
-	const uint32_t in = (uint32_t)i & 63u;
-	const uint32_t tiles_per_row = w >> 3;
-	const unsigned long long ty = tile / tiles_per_row;
-	const uint32_t tx = (uint32_t)(tile - ty * tiles_per_row);
-	const unsigned long long x = (unsigned long long)tx * 8u + (in & 7u);
-	const unsigned long long y = ty * 8u + (in >> 3);
-	return y * w + x;
-}
-
 template <int MODE /*0 closest, 1 any*/, bool COUNT>
 __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 {
@@ -140,6 +102,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 	uint32_t top = RTK_REF_NONE;
 	uint32_t sp = 0;
 	uint32_t c_nodes = 0, c_leaves = 0, c_tris = 0, c_spills = 0;
+	unsigned long long w_node_steps = 0, w_tri_steps = 0;   // COUNT only: wave-level loop trips (divergence diagnostics)
 	// A ray is "special" if its slab products can be NaN (0*inf) or its inputs are not finite;
 	// only then does the SSE operand order of min/max matter (see node step).
 	bool special = false;
@@ -221,6 +184,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			const unsigned long long m_node = __ballot(want_node);
 			if (m_node == 0ull) break;
 			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
+			if (COUNT) w_node_steps++;
 			if (!want_node) continue;
 			const uint32_t a_node = top << 7;
 			f32x4 nx, fx, ny, fy, nz, fz;
@@ -307,6 +271,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			while (i < n) {
 				f32x4 A, B, C;
 				load_tri(tris, (slot0 + i) * 48u, A, B, C);
+				if (COUNT && lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) w_tri_steps++;
 				if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
 				if ((i & 3u) == 0u) {
 					if (redo) { force = true; redo = false; }
@@ -409,6 +374,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			active = false;
 		}
 	}
+	if (COUNT) {
+		// wave-level trip counts: node steps are counted on a wave-uniform variable, triangle steps
+		// on whichever lane was first in the leaf loop; rays/64 gives steps per 64 rays
+		if (lane == 0) atomicAdd(p.counter + 7, w_node_steps);
+		atomicAdd(p.counter + 8, w_tri_steps);
+	}
 }
 
 // Full rtk_hit from a compact record (rtk.c:372-380 copy-out).
@@ -487,22 +458,28 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		if (opts->struct_size >= 28 && opts->node_exit) p.node_exit = opts->node_exit > 64 ? 64 : opts->node_exit;
 	}
 
+	// image-shaped closest-hit batches go to the wave-packet kernel (rtk_trace_packet.hip)
+	const bool packet = !any_hit && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
+
 	static int occ[2][2] = { { 0, 0 }, { 0, 0 } };
-	int &o = occ[any_hit ? 1 : 0][counted ? 1 : 0];
+	static int occ_packet[2] = { 0, 0 };
+	int &o = packet ? occ_packet[counted ? 1 : 0] : occ[any_hit ? 1 : 0][counted ? 1 : 0];
 	if (o == 0) {
-		o = any_hit ? (counted ? occupancy_blocks<1, true>() : occupancy_blocks<1, false>())
-		            : (counted ? occupancy_blocks<0, true>() : occupancy_blocks<0, false>());
+		if (packet) o = rtk_packet_occupancy(counted != nullptr);
+		else o = any_hit ? (counted ? occupancy_blocks<1, true>() : occupancy_blocks<1, false>())
+		                 : (counted ? occupancy_blocks<0, true>() : occupancy_blocks<0, false>());
 	}
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)o) blocks_per_cu = (uint32_t)o;
 
 	const size_t blocks_needed = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
-	size_t blocks = p.dynamic ? (size_t)ds->num_cus * blocks_per_cu : blocks_needed;
+	size_t blocks = (p.dynamic || packet) ? (size_t)ds->num_cus * blocks_per_cu : blocks_needed;
 	if (blocks > blocks_needed) blocks = blocks_needed;
 	if (blocks > 0x7fffffffu) { rtk_set_error("rtk_dev_trace: batch too large for one launch"); return RTK_AMD_ERR_BAD_ARG; }
 
 	// spill area for rays whose stack outgrows LDS
 	const size_t lanes = blocks * BLOCK_THREADS;
-	const size_t spill_cap = ds->stack_entries > LDS_STACK ? ds->stack_entries - LDS_STACK : 0;
+	const size_t lds_entries = packet ? 32 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
+	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
 	if (spill_cap && (ds->spill_lanes < lanes || ds->spill_entries_per_lane < spill_cap)) {
 		if (ds->d_spill) (void)hipFree(ds->d_spill);
 		ds->d_spill = nullptr;
@@ -515,9 +492,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.spill_cap = (uint32_t)spill_cap;
 	p.counter = ds->d_counter;
 
-	RTK_HIP_CHECK(hipMemsetAsync(ds->d_counter, 0, 8 * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	RTK_HIP_CHECK(hipMemsetAsync(ds->d_counter, 0, 16 * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
 	const dim3 grid((unsigned)blocks), block(BLOCK_THREADS);
-	if (any_hit) {
+	if (packet) {
+		rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
+	} else if (any_hit) {
 		if (counted) hipLaunchKernelGGL((rtk_trace_kernel<1, true>), grid, block, 0, stream, p);
 		else hipLaunchKernelGGL((rtk_trace_kernel<1, false>), grid, block, 0, stream, p);
 	} else {
@@ -526,11 +505,12 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	}
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	if (counted) {
-		unsigned long long c[8];
+		unsigned long long c[16];
 		RTK_HIP_CHECK(hipMemcpyAsync(c, ds->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
 		counted->rays = c[1]; counted->nodes = c[2]; counted->leaves = c[3];
 		counted->triangles = c[4]; counted->hits = c[5]; counted->stack_spills = c[6];
+		counted->wave_node_steps = c[7]; counted->wave_triangle_steps = c[8]; counted->wave_rays = c[9];
 	}
 	return RTK_AMD_OK;
 }

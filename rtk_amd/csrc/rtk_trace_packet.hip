@@ -1,0 +1,380 @@
+// rtk_trace_packet.hip -- wave-packet BVH4 traversal for image-shaped (coherent) batches.
+//
+// Same results as rtk_trace_kernel (rtk_trace.hip) -- the per-lane arithmetic of the slab
+// test (rtk.c:457-472), the triangle test (rtk.c:284-364) and the group-of-four double
+// precision rule (rtk.c:302-336) is identical -- but the 64 rays of an 8x8 pixel tile walk
+// the tree TOGETHER:
+//   * the node / triangle being processed is wave-uniform, so its 128 B / 48 B come through
+//     the scalar cache (s_load_dwordx16) into SGPRs: one request per wave instead of one
+//     per lane, no per-lane address arithmetic, and the data feeds VALU ops as SGPR operands;
+//   * the traversal stack is wave-uniform and lives in ONE VGPR (entry i in lane i,
+//     v_writelane/v_readlane); only the per-lane entry distance of a pushed child goes to
+//     LDS ([entry][lane] floats) so that each lane culls exactly like its own traversal would
+//     (rtk.c:432: skip an entry that starts behind the lane's current hit);
+//   * every lane keeps its own "live" bit: it takes part in a node or leaf only if its own
+//     slab test admitted that child -- per-lane visit semantics, packet-wide control flow;
+//   * child order is taken from the first lane that hits (scalar sort on SALU).
+// Per-lane traversal wastes ~55 % (nodes) and ~80 % (triangles) of the lanes on config 2
+// because neighbouring rays reach leaves at different times (profiles/r01b_coherent_*);
+// a tile of the 4096^2 frame is ~3e-3 wide against ~2e-2 triangles, so a packet visits
+// little more than a single ray does.
+//
+// FLOATING POINT: compiled with -ffp-contract=off like rtk_trace.hip.
+#include "rtk_dev.h"
+#include "rtk_trace_shared.h"
+
+#include <math.h>
+
+#define PK_LDS_STACK 32            // per-lane entry distances held in LDS
+#define PK_WAVE_STACK 64           // wave-uniform references held in one VGPR
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float asf(int v) { return __int_as_float(v); }
+
+// 128 B node through the scalar cache: lo = bx[0],bx[1],by[0],by[1]; hi = bz[0],bz[1],child,pad
+__device__ __forceinline__ void s_load_node(const char *addr, i32x16 &lo, i32x16 &hi)
+{
+	asm volatile(
+		"s_load_dwordx16 %0, %2, 0x0\n\t"
+		"s_load_dwordx16 %1, %2, 0x40\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=&s"(lo), "=&s"(hi) : "s"(addr) : "memory");
+}
+
+// 48 B triangle: a = v0.xyz, prim, v1.xyz, flags; b = v2.xyz, spare
+__device__ __forceinline__ void s_load_tri(const char *addr, i32x8 &a, i32x4 &b)
+{
+	asm volatile(
+		"s_load_dwordx8 %0, %2, 0x0\n\t"
+		"s_load_dwordx4 %1, %2, 0x20\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=&s"(a), "=&s"(b) : "s"(addr) : "memory");
+}
+
+__device__ __forceinline__ uint32_t stack_write(uint32_t stack, uint32_t value, uint32_t entry, uint32_t lane)
+{
+	// (v_writelane_b32 with an SGPR value AND an SGPR lane select breaks the one-SGPR constant-bus rule)
+	return lane == entry ? value : stack;
+}
+
+__device__ __forceinline__ int sort_key(float f)
+{
+	// float order -> signed int order
+	const int b = __float_as_int(f);
+	return b ^ ((b >> 31) & 0x7fffffff);
+}
+
+struct PkLane {
+	// ray
+	float ox, oy, oz, rdx, rdy, rdz, tmin, tmax;
+	float sox, soy, soz, shx, shy, shz;
+	bool kz0, kz1, sx, sy, sz;
+	// best hit
+	float t, u, v;
+	uint32_t prim;
+};
+
+// One triangle against every live lane. DBL: use the double-precision edge functions.
+// Returns (per lane) whether a float edge function was exactly zero.
+template <bool DBL>
+__device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, bool kz_uniform, uint32_t ukz, const i32x8 &a, const i32x4 &b)
+{
+	float ax, ay, az, bx, by, bz, cx, cy, cz;
+	if (kz_uniform) {
+		// (kx,ky,kz) is the same for every lane: permute on the scalar side (rtk.c:232-243)
+		const int p0x = ukz == 0 ? a[1] : (ukz == 1 ? a[2] : a[0]);
+		const int p0y = ukz == 0 ? a[2] : (ukz == 1 ? a[0] : a[1]);
+		const int p0z = ukz == 0 ? a[0] : (ukz == 1 ? a[1] : a[2]);
+		const int p1x = ukz == 0 ? a[5] : (ukz == 1 ? a[6] : a[4]);
+		const int p1y = ukz == 0 ? a[6] : (ukz == 1 ? a[4] : a[5]);
+		const int p1z = ukz == 0 ? a[4] : (ukz == 1 ? a[5] : a[6]);
+		const int p2x = ukz == 0 ? b[1] : (ukz == 1 ? b[2] : b[0]);
+		const int p2y = ukz == 0 ? b[2] : (ukz == 1 ? b[0] : b[1]);
+		const int p2z = ukz == 0 ? b[0] : (ukz == 1 ? b[1] : b[2]);
+		ax = asf(p0x); ay = asf(p0y); az = asf(p0z);
+		bx = asf(p1x); by = asf(p1y); bz = asf(p1z);
+		cx = asf(p2x); cy = asf(p2y); cz = asf(p2z);
+	} else {
+		const float A0 = asf(a[0]), A1 = asf(a[1]), A2 = asf(a[2]);
+		const float B0 = asf(a[4]), B1 = asf(a[5]), B2 = asf(a[6]);
+		const float C0 = asf(b[0]), C1 = asf(b[1]), C2 = asf(b[2]);
+		ax = L.kz0 ? A1 : (L.kz1 ? A2 : A0); ay = L.kz0 ? A2 : (L.kz1 ? A0 : A1); az = L.kz0 ? A0 : (L.kz1 ? A1 : A2);
+		bx = L.kz0 ? B1 : (L.kz1 ? B2 : B0); by = L.kz0 ? B2 : (L.kz1 ? B0 : B1); bz = L.kz0 ? B0 : (L.kz1 ? B1 : B2);
+		cx = L.kz0 ? C1 : (L.kz1 ? C2 : C0); cy = L.kz0 ? C2 : (L.kz1 ? C0 : C1); cz = L.kz0 ? C0 : (L.kz1 ? C1 : C2);
+	}
+	// move the origin, shear (rtk.c:256-292)
+	const float v0x = ax - L.sox, v0y = ay - L.soy, v0z = az - L.soz;
+	const float v1x = bx - L.sox, v1y = by - L.soy, v1z = bz - L.soz;
+	const float v2x = cx - L.sox, v2y = cy - L.soy, v2z = cz - L.soz;
+	const float x0 = v0x + L.shx * v0z, y0 = v0y + L.shy * v0z, z0 = L.shz * v0z;
+	const float x1 = v1x + L.shx * v1z, y1 = v1y + L.shy * v1z, z1 = L.shz * v1z;
+	const float x2 = v2x + L.shx * v2z, y2 = v2y + L.shy * v2z, z2 = L.shz * v2z;
+	float u, v, w;
+	bool zero = false;
+	if (DBL) {
+		const double xd0 = x0, yd0 = y0, xd1 = x1, yd1 = y1, xd2 = x2, yd2 = y2;   // rtk.c:307-335
+		u = (float)(xd1 * yd2 - yd1 * xd2);
+		v = (float)(xd2 * yd0 - yd2 * xd0);
+		w = (float)(xd0 * yd1 - yd0 * xd1);
+	} else {
+		u = x1 * y2 - y1 * x2;                                                    // rtk.c:298-300
+		v = x2 * y0 - y2 * x0;
+		w = x0 * y1 - y0 * x1;
+		zero = u == 0.0f || v == 0.0f || w == 0.0f;
+	}
+	const bool neg = sse_min(sse_min(u, v), w) < 0.0f;                           // rtk.c:340-342
+	const bool pos = sse_max(sse_max(u, v), w) > 0.0f;
+	const float det = (u + v) + w;                                               // rtk.c:346-353
+	const float rcp = 1.0f / det;
+	float zz = u * z0;
+	zz = zz + v * z1;
+	zz = zz + w * z2;
+	const float t = zz * rcp;
+	const uint32_t prim = (uint32_t)a[3];
+	const bool ok = lanes && !(neg && pos) && t > L.tmin && t < L.tmax;          // rtk.c:354
+	if (ok && (t < L.t || (t == L.t && prim < L.prim))) {                        // rtk.c:371 + canonical ties
+		L.t = t; L.u = u * rcp; L.v = v * rcp; L.prim = prim;
+	}
+	return zero;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 mk2(int a, int b) { f32x2 r; r.x = asf(a); r.y = asf(b); return r; }
+
+// Slab test of children c0 = 2*PAIR and c0+1 for every lane; node data in SGPRs. Two children at
+// a time so that the (bound - origin) * rcp of rtk.c:458-463 maps onto v_pk_add_f32 / v_pk_mul_f32.
+// Writes the per-lane entry distance, or NaN where the lane does not enter the child.
+template <bool UNIFORM_SIGN, bool FAST>
+__device__ __forceinline__ void pk_slab2(const PkLane &L, const i32x16 &lo, const i32x16 &hi, const int c0,
+	bool usx, bool usy, bool usz, bool live, float &pay0, float &pay1)
+{
+	f32x2 nx, fx, ny, fy, nz, fz;
+	const f32x2 bx0 = mk2(lo[c0], lo[c0 + 1]), bx1 = mk2(lo[4 + c0], lo[5 + c0]);
+	const f32x2 by0 = mk2(lo[8 + c0], lo[9 + c0]), by1 = mk2(lo[12 + c0], lo[13 + c0]);
+	const f32x2 bz0 = mk2(hi[c0], hi[c0 + 1]), bz1 = mk2(hi[4 + c0], hi[5 + c0]);
+	if (UNIFORM_SIGN) {
+		// near/far planes picked on the scalar side by the (wave-uniform) direction sign bits
+		nx = ((usx ? bx1 : bx0) - L.ox) * L.rdx; fx = ((usx ? bx0 : bx1) - L.ox) * L.rdx;
+		ny = ((usy ? by1 : by0) - L.oy) * L.rdy; fy = ((usy ? by0 : by1) - L.oy) * L.rdy;
+		nz = ((usz ? bz1 : bz0) - L.oz) * L.rdz; fz = ((usz ? bz0 : bz1) - L.oz) * L.rdz;
+	} else {
+		const f32x2 x0 = (bx0 - L.ox) * L.rdx, x1 = (bx1 - L.ox) * L.rdx;
+		const f32x2 y0 = (by0 - L.oy) * L.rdy, y1 = (by1 - L.oy) * L.rdy;
+		const f32x2 z0 = (bz0 - L.oz) * L.rdz, z1 = (bz1 - L.oz) * L.rdz;
+		nx = L.sx ? x1 : x0; fx = L.sx ? x0 : x1;
+		ny = L.sy ? y1 : y0; fy = L.sy ? y0 : y1;
+		nz = L.sz ? z1 : z0; fz = L.sz ? z0 : z1;
+	}
+	float tn0, tf0, tn1, tf1;
+	if (FAST) {
+		tn0 = fmaxf(fmaxf(fmaxf(nx.x, ny.x), nz.x), L.tmin); tf0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), L.t);
+		tn1 = fmaxf(fmaxf(fmaxf(nx.y, ny.y), nz.y), L.tmin); tf1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), L.t);
+	} else {
+		tn0 = sse_max(sse_max(nx.x, ny.x), sse_max(nz.x, L.tmin)); tf0 = sse_min(sse_min(fx.x, fy.x), sse_min(fz.x, L.t));   // rtk.c:464-465
+		tn1 = sse_max(sse_max(nx.y, ny.y), sse_max(nz.y, L.tmin)); tf1 = sse_min(sse_min(fx.y, fy.y), sse_min(fz.y, L.t));
+	}
+	const float miss = __builtin_nanf("");
+	pay0 = (live && tn0 <= tf0 && (uint32_t)hi[8 + c0] != RTK_REF_NONE) ? tn0 : miss;
+	pay1 = (live && tn1 <= tf1 && (uint32_t)hi[9 + c0] != RTK_REF_NONE) ? tn1 : miss;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK_THREADS) rtk_trace_packet_kernel(TraceParams p)
+{
+	__shared__ float s_t[TRACE_WAVES_PER_BLOCK][PK_LDS_STACK][64];
+
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	float (*lds_t)[64] = s_t[wave];
+	const uint32_t glane = blockIdx.x * TRACE_BLOCK_THREADS + threadIdx.x;
+	float *const spill_t = reinterpret_cast<float *>(p.spill);
+	const char *const nodes = reinterpret_cast<const char *>(p.sc.nodes);
+	const char *const tris = reinterpret_cast<const char *>(p.sc.tris);
+
+	for (;;) {
+		// ------------------------------------------------------------ next tile of 64 rays
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(p.counter, 64ull);
+		base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+			(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+		if (base >= p.n) break;
+		const unsigned long long idx = base + lane;
+		const bool alive = idx < p.n;
+		const unsigned long long ray_index = map_index(alive ? idx : base, p.image_w, p.image_h);
+
+		PkLane L;
+		{
+			const float4 r0 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.rays + ray_index));
+			const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
+			L.ox = r0.x; L.oy = r0.y; L.oz = r0.z;
+			const float dx = r0.w, dy = r1.x, dz = r1.y;
+			L.tmin = r1.z; L.tmax = r1.w;
+			// rtk.c:550-566
+			const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+			const float m = sse_max(sse_max(ax, ay), az);
+			L.kz0 = ax == m;
+			L.kz1 = !L.kz0 && ay == m;
+			const float dkx = L.kz0 ? dy : (L.kz1 ? dz : dx);
+			const float dky = L.kz0 ? dz : (L.kz1 ? dx : dy);
+			const float dkz = L.kz0 ? dx : (L.kz1 ? dy : dz);
+			L.shx = -dkx / dkz; L.shy = -dky / dkz; L.shz = 1.0f / dkz;
+			L.sox = L.kz0 ? L.oy : (L.kz1 ? L.oz : L.ox);
+			L.soy = L.kz0 ? L.oz : (L.kz1 ? L.ox : L.oy);
+			L.soz = L.kz0 ? L.ox : (L.kz1 ? L.oy : L.oz);
+			L.rdx = 1.0f / dx; L.rdy = 1.0f / dy; L.rdz = 1.0f / dz;             // rtk.c:410
+			L.sx = __float_as_uint(dx) >> 31; L.sy = __float_as_uint(dy) >> 31; L.sz = __float_as_uint(dz) >> 31;
+			L.t = L.tmax; L.u = 0.0f; L.v = 0.0f; L.prim = RTK_PRIM_NONE;
+		}
+		const bool special = !(isfinite(L.rdx) && isfinite(L.rdy) && isfinite(L.rdz) && L.rdx != 0.0f && L.rdy != 0.0f && L.rdz != 0.0f &&
+			isfinite(L.ox) && isfinite(L.oy) && isfinite(L.oz) && L.tmin == L.tmin && L.tmax == L.tmax);
+		// wave-uniform facts about the packet
+		const unsigned long long m_alive = __ballot(alive);
+		const bool wave_fast = __ballot(alive && special) == 0ull;
+		const unsigned long long bsx = __ballot(alive && L.sx), bsy = __ballot(alive && L.sy), bsz = __ballot(alive && L.sz);
+		const bool sign_uniform = (bsx == 0ull || bsx == m_alive) && (bsy == 0ull || bsy == m_alive) && (bsz == 0ull || bsz == m_alive);
+		const bool usx = bsx != 0ull, usy = bsy != 0ull, usz = bsz != 0ull;
+		const unsigned long long bk0 = __ballot(alive && L.kz0), bk1 = __ballot(alive && L.kz1);
+		const bool kz_uniform = (bk0 == 0ull || bk0 == m_alive) && (bk1 == 0ull || bk1 == m_alive);
+		const uint32_t ukz = bk0 != 0ull ? 0u : (bk1 != 0ull ? 1u : 2u);
+
+		uint32_t c_nodes = 0, c_leaves = 0, c_tris = 0, c_spills = 0;
+		uint32_t stack = 0;          // wave-uniform references, entry i in lane i
+		uint32_t sp = 0;             // wave-uniform
+		uint32_t top = 0;            // wave-uniform: root
+		bool live = alive;           // per lane
+
+		for (;;) {
+			bool pop = false;
+			if ((int32_t)top >= 0) {
+				// ---------------------------------------------------- node (wave-uniform)
+				i32x16 lo, hi;
+				s_load_node(nodes + (size_t)top * 128u, lo, hi);
+				if (COUNT && live) c_nodes++;
+				if (COUNT && lane == 0) atomicAdd(p.counter + 7, 1ull);
+				// per lane: entry distance of each child, NaN = this lane does not enter it
+				float pay[4];
+				if (sign_uniform) {
+					if (wave_fast) { pk_slab2<true, true>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<true, true>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
+					else { pk_slab2<true, false>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<true, false>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
+				} else {
+					if (wave_fast) { pk_slab2<false, true>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<false, true>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
+					else { pk_slab2<false, false>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<false, false>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
+				}
+				// wave-level: which children does anybody enter, and in which order (entry distance of
+				// the first live lane; a child nobody enters sorts last)
+				const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
+				int key[4];
+				uint32_t ref[4] = { (uint32_t)hi[8], (uint32_t)hi[9], (uint32_t)hi[10], (uint32_t)hi[11] };
+				uint32_t n_any = 0;
+#pragma unroll
+				for (int c = 0; c < 4; c++) {
+					const bool any = __ballot(pay[c] == pay[c]) != 0ull;
+					const float kf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay[c]), lead));
+					// the lead lane may itself miss this child (NaN): then order it behind its own hits
+					key[c] = any ? (kf == kf ? sort_key(kf) : 0x7ffffffe) : 0x7fffffff;
+					n_any += any ? 1u : 0u;
+				}
+				// sorting network; keys and references on the scalar side, the per-lane payload follows with
+				// wave-uniform select conditions
+#define PK_CSWAP(a, b) { const bool s_ = key[b] < key[a]; const int ka_ = s_ ? key[b] : key[a], kb_ = s_ ? key[a] : key[b]; \
+	const uint32_t ra_ = s_ ? ref[b] : ref[a], rb_ = s_ ? ref[a] : ref[b]; const float pa_ = s_ ? pay[b] : pay[a], pb_ = s_ ? pay[a] : pay[b]; \
+	key[a] = ka_; key[b] = kb_; ref[a] = ra_; ref[b] = rb_; pay[a] = pa_; pay[b] = pb_; }
+				PK_CSWAP(0, 1) PK_CSWAP(2, 3) PK_CSWAP(0, 2) PK_CSWAP(1, 3) PK_CSWAP(1, 2)
+#undef PK_CSWAP
+				if (n_any == 0u) {
+					pop = true;
+				} else {
+					// far children first so that the nearest is popped first (rtk.c:520-535)
+#pragma unroll
+					for (int i = 3; i >= 1; i--) {
+						if (n_any > (uint32_t)i) {
+							if (sp < PK_LDS_STACK) lds_t[sp][lane] = pay[i];
+							else if (sp - PK_LDS_STACK < p.spill_cap) { spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane] = pay[i]; if (COUNT) c_spills++; }
+							stack = stack_write(stack, ref[i], sp, lane);
+							sp++;
+						}
+					}
+					live = pay[0] == pay[0];
+					top = ref[0];
+				}
+			} else {
+				// ---------------------------------------------------- leaf (wave-uniform)
+				const uint32_t slot0 = top & 0x7fffffffu;
+				i32x8 ta;
+				i32x4 tb;
+				s_load_tri(tris + (size_t)slot0 * 48u, ta, tb);
+				const uint32_t n = (uint32_t)tb[3];                                // leaf size rides in the first record
+				if (COUNT && live) c_leaves++;
+				for (uint32_t g = 0; g < n; g += 4u) {
+					const uint32_t m = n - g < 4u ? n - g : 4u;
+					const bool force = m < 4u;                                     // padding slots make the whole group double (rtk.c:306)
+					const float sn_t = L.t, sn_u = L.u, sn_v = L.v;
+					const uint32_t sn_prim = L.prim;
+					bool zero_seen = false;
+					for (uint32_t j = 0; j < m; j++) {
+						if (g + j != 0u) s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
+						if (COUNT && live) c_tris++;
+						if (COUNT && lane == 0) atomicAdd(p.counter + 8, 1ull);
+						if (force) pk_triangle<true>(L, live, kz_uniform, ukz, ta, tb);
+						else zero_seen |= pk_triangle<false>(L, live, kz_uniform, ukz, ta, tb);
+					}
+					const bool redo = live && zero_seen;
+					if (__ballot(redo) != 0ull) {
+						// an exact zero in a full group: those lanes redo the group in double (rtk.c:302-336)
+						if (redo) { L.t = sn_t; L.u = sn_u; L.v = sn_v; L.prim = sn_prim; }
+						for (uint32_t j = 0; j < m; j++) {
+							s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
+							pk_triangle<true>(L, redo, kz_uniform, ukz, ta, tb);
+						}
+					}
+				}
+				pop = true;
+			}
+			if (pop) {
+				// pop until some lane still needs the entry (rtk.c:432, canonical: skip only if it starts BEHIND the hit)
+				bool done = false;
+				for (;;) {
+					if (sp == 0u) { done = true; break; }
+					sp--;
+					const float te = sp < PK_LDS_STACK ? lds_t[sp][lane] : spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane];
+					live = alive && te <= L.t;
+					if (__ballot(live) != 0ull) {
+						top = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
+						break;
+					}
+				}
+				if (done) break;
+			}
+		}
+
+		if (alive) {
+			*reinterpret_cast<float4 *>(p.hits + ray_index) = make_float4(L.t, L.u, L.v, __uint_as_float(L.prim));
+			if (COUNT) {
+				atomicAdd(p.counter + 1, 1ull);
+				atomicAdd(p.counter + 2, (unsigned long long)c_nodes);
+				atomicAdd(p.counter + 3, (unsigned long long)c_leaves);
+				atomicAdd(p.counter + 4, (unsigned long long)c_tris);
+				atomicAdd(p.counter + 5, L.prim != RTK_PRIM_NONE ? 1ull : 0ull);
+				atomicAdd(p.counter + 6, (unsigned long long)c_spills);
+			}
+		}
+	}
+}
+
+int rtk_packet_occupancy(bool counted)
+{
+	int nb = 0;
+	hipError_t e = counted ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk_trace_packet_kernel<true>, TRACE_BLOCK_THREADS, 0)
+	                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk_trace_packet_kernel<false>, TRACE_BLOCK_THREADS, 0);
+	return (e == hipSuccess && nb >= 1) ? nb : 1;
+}
+
+void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool counted)
+{
+	if (counted) hipLaunchKernelGGL((rtk_trace_packet_kernel<true>), dim3(blocks), dim3(TRACE_BLOCK_THREADS), 0, stream, p);
+	else hipLaunchKernelGGL((rtk_trace_packet_kernel<false>), dim3(blocks), dim3(TRACE_BLOCK_THREADS), 0, stream, p);
+}

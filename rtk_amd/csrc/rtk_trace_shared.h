@@ -1,0 +1,52 @@
+// rtk_trace_shared.h -- pieces shared by the two traversal kernels (rtk_trace.hip: one ray
+// per lane; rtk_trace_packet.hip: one 8x8 tile per wave).
+#pragma once
+
+#include "rtk_dev.h"
+
+#define LDS_STACK 16           // entries per lane held in LDS
+#define TRACE_WAVES_PER_BLOCK 4
+#define TRACE_BLOCK_THREADS (64 * TRACE_WAVES_PER_BLOCK)
+#define WAVES_PER_BLOCK TRACE_WAVES_PER_BLOCK
+#define BLOCK_THREADS TRACE_BLOCK_THREADS
+#define RAY_CHUNK 64           // rays taken from the global pool per atomic
+
+struct TraceParams {
+	DevSceneView sc;
+	const rtk_ray *rays;
+	rtk_hit_record *hits;
+	uint8_t *occluded;
+	unsigned long long *counter;   // [0] pool head, [1..6] visit counters
+	uint2 *spill;
+	unsigned long long n;
+	uint32_t spill_stride;         // lanes in the launch
+	uint32_t spill_cap;            // entries per lane in spill
+	uint32_t image_w, image_h;     // 0 = no tiling
+	uint32_t refill_min;
+	uint32_t dynamic;
+	uint32_t node_exit;            // leave the node loop when fewer lanes than this still need node steps and a leaf is waiting
+};
+
+// _mm_min_ps/_mm_max_ps semantics (second operand when the compare is false, NaN included)
+__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
+
+
+// Row-major image -> 8x8 pixel tiles, so that the 64 lanes of a wave share BVH nodes.
+__device__ __forceinline__ unsigned long long map_index(unsigned long long i, uint32_t w, uint32_t h)
+{
+	if (w == 0) return i;
+	const unsigned long long tile = i >> 6;
+	const uint32_t in = (uint32_t)i & 63u;
+	const uint32_t tiles_per_row = w >> 3;
+	const unsigned long long ty = tile / tiles_per_row;
+	const uint32_t tx = (uint32_t)(tile - ty * tiles_per_row);
+	const unsigned long long x = (unsigned long long)tx * 8u + (in & 7u);
+	const unsigned long long y = ty * 8u + (in >> 3);
+	return y * w + x;
+}
+
+
+// rtk_trace_packet.hip
+int rtk_packet_occupancy(bool counted);
+void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool counted);

@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-KERNEL = "rtk_trace_kernel<0, false>"
+KERNEL = os.environ.get("RTK_PROFILE_KERNEL", "rtk_trace_kernel<0, false>")
 
 
 def main():

@@ -54,6 +54,7 @@ def test_coherent_full_batch(api, oracle, scene):
     # launch modes agree on all 2^24 rays
     assert ds.trace(rays, full=False).tobytes() == rec.tobytes()
     assert ds.trace(rays, opts=api.make_opts(node_exit=1, refill_min=64), full=False).tobytes() == rec.tobytes()
+    assert ds.trace(rays, opts=api.make_opts(image=(4096, 4096), no_packet=True), full=False).tobytes() == rec.tobytes()
     # any-hit over the same interval
     assert (ds.trace_any(rays) == (rec["prim"] != 0xFFFFFFFF)).all()
     # strided sample: identical to the oracle on the exported BVH
