@@ -478,7 +478,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 
 	// spill area for rays whose stack outgrows LDS
 	const size_t lanes = blocks * BLOCK_THREADS;
-	const size_t lds_entries = packet ? 32 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
+	const size_t lds_entries = packet ? 16 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
 	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
 	if (spill_cap && (ds->spill_lanes < lanes || ds->spill_entries_per_lane < spill_cap)) {
 		if (ds->d_spill) (void)hipFree(ds->d_spill);

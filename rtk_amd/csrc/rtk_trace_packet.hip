@@ -25,8 +25,11 @@
 
 #include <math.h>
 
-#define PK_LDS_STACK 32            // per-lane entry distances held in LDS
+#define PK_LDS_STACK 16            // per-lane entry distances held in LDS
 #define PK_WAVE_STACK 64           // wave-uniform references held in one VGPR
+#ifndef PK_MIN_WAVES
+#define PK_MIN_WAVES 5             // waves per SIMD the register allocator must leave room for
+#endif
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -34,14 +37,25 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float asf(int v) { return __int_as_float(v); }
 
-// 128 B node through the scalar cache: lo = bx[0],bx[1],by[0],by[1]; hi = bz[0],bz[1],child,pad
-__device__ __forceinline__ void s_load_node(const char *addr, i32x16 &lo, i32x16 &hi)
+// 128 B node through the scalar cache. The six plane rows are fetched at byte offsets chosen once
+// per packet from the direction sign bits (near row first), exactly like the reference indexes
+// bounds_x[sign_x] (rtk.c:458-463): no selects afterwards.
+struct PkNode { i32x4 nx, fx, ny, fy, nz, fz, ch; };
+__device__ __forceinline__ void s_load_node(const char *addr, uint32_t onx, uint32_t ofx, uint32_t ony, uint32_t ofy,
+	uint32_t onz, uint32_t ofz, PkNode &n)
 {
 	asm volatile(
-		"s_load_dwordx16 %0, %2, 0x0\n\t"
-		"s_load_dwordx16 %1, %2, 0x40\n\t"
+		"s_load_dwordx4 %0, %7, %8\n\t"
+		"s_load_dwordx4 %1, %7, %9\n\t"
+		"s_load_dwordx4 %2, %7, %10\n\t"
+		"s_load_dwordx4 %3, %7, %11\n\t"
+		"s_load_dwordx4 %4, %7, %12\n\t"
+		"s_load_dwordx4 %5, %7, %13\n\t"
+		"s_load_dwordx4 %6, %7, 0x60\n\t"
 		"s_waitcnt lgkmcnt(0)"
-		: "=&s"(lo), "=&s"(hi) : "s"(addr) : "memory");
+		: "=&s"(n.nx), "=&s"(n.fx), "=&s"(n.ny), "=&s"(n.fy), "=&s"(n.nz), "=&s"(n.fz), "=&s"(n.ch)
+		: "s"(addr), "s"(onx), "s"(ofx), "s"(ony), "s"(ofy), "s"(onz), "s"(ofz)
+		: "memory");
 }
 
 // 48 B triangle: a = v0.xyz, prim, v1.xyz, flags; b = v2.xyz, spare
@@ -78,25 +92,25 @@ struct PkLane {
 };
 
 // One triangle against every live lane. DBL: use the double-precision edge functions.
+// KZ = 0,1,2: every lane of the packet has this dominant axis, the permutation to (kx,ky,kz)
+// (rtk.c:232-243) is a compile-time pick of scalar registers; KZ = 3: per lane.
 // Returns (per lane) whether a float edge function was exactly zero.
-template <bool DBL>
-__device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, bool kz_uniform, uint32_t ukz, const i32x8 &a, const i32x4 &b)
+template <bool DBL, int KZ>
+__device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, const i32x8 &a, const i32x4 &b)
 {
 	float ax, ay, az, bx, by, bz, cx, cy, cz;
-	if (kz_uniform) {
-		// (kx,ky,kz) is the same for every lane: permute on the scalar side (rtk.c:232-243)
-		const int p0x = ukz == 0 ? a[1] : (ukz == 1 ? a[2] : a[0]);
-		const int p0y = ukz == 0 ? a[2] : (ukz == 1 ? a[0] : a[1]);
-		const int p0z = ukz == 0 ? a[0] : (ukz == 1 ? a[1] : a[2]);
-		const int p1x = ukz == 0 ? a[5] : (ukz == 1 ? a[6] : a[4]);
-		const int p1y = ukz == 0 ? a[6] : (ukz == 1 ? a[4] : a[5]);
-		const int p1z = ukz == 0 ? a[4] : (ukz == 1 ? a[5] : a[6]);
-		const int p2x = ukz == 0 ? b[1] : (ukz == 1 ? b[2] : b[0]);
-		const int p2y = ukz == 0 ? b[2] : (ukz == 1 ? b[0] : b[1]);
-		const int p2z = ukz == 0 ? b[0] : (ukz == 1 ? b[1] : b[2]);
-		ax = asf(p0x); ay = asf(p0y); az = asf(p0z);
-		bx = asf(p1x); by = asf(p1y); bz = asf(p1z);
-		cx = asf(p2x); cy = asf(p2y); cz = asf(p2z);
+	if (KZ == 0) {
+		ax = asf(a[1]); ay = asf(a[2]); az = asf(a[0]);
+		bx = asf(a[5]); by = asf(a[6]); bz = asf(a[4]);
+		cx = asf(b[1]); cy = asf(b[2]); cz = asf(b[0]);
+	} else if (KZ == 1) {
+		ax = asf(a[2]); ay = asf(a[0]); az = asf(a[1]);
+		bx = asf(a[6]); by = asf(a[4]); bz = asf(a[5]);
+		cx = asf(b[2]); cy = asf(b[0]); cz = asf(b[1]);
+	} else if (KZ == 2) {
+		ax = asf(a[0]); ay = asf(a[1]); az = asf(a[2]);
+		bx = asf(a[4]); by = asf(a[5]); bz = asf(a[6]);
+		cx = asf(b[0]); cy = asf(b[1]); cz = asf(b[2]);
 	} else {
 		const float A0 = asf(a[0]), A1 = asf(a[1]), A2 = asf(a[2]);
 		const float B0 = asf(a[4]), B1 = asf(a[5]), B2 = asf(a[6]);
@@ -135,9 +149,10 @@ __device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, bool kz_unifo
 	const float t = zz * rcp;
 	const uint32_t prim = (uint32_t)a[3];
 	const bool ok = lanes && !(neg && pos) && t > L.tmin && t < L.tmax;          // rtk.c:354
-	if (ok && (t < L.t || (t == L.t && prim < L.prim))) {                        // rtk.c:371 + canonical ties
-		L.t = t; L.u = u * rcp; L.v = v * rcp; L.prim = prim;
-	}
+	const bool take = ok && (t < L.t || (t == L.t && prim < L.prim));            // rtk.c:371 + canonical ties
+	// selects, not branches: a branch costs three exec-mask regions per triangle on the scalar unit
+	const float nu = u * rcp, nv = v * rcp;
+	L.t = take ? t : L.t; L.u = take ? nu : L.u; L.v = take ? nv : L.v; L.prim = take ? prim : L.prim;
 	return zero;
 }
 
@@ -145,29 +160,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 mk2(int a, int b) { f32x2 r; r.x = asf(a); r.y = asf(b); return r; }
 
-// Slab test of children c0 = 2*PAIR and c0+1 for every lane; node data in SGPRs. Two children at
-// a time so that the (bound - origin) * rcp of rtk.c:458-463 maps onto v_pk_add_f32 / v_pk_mul_f32.
-// Writes the per-lane entry distance, or NaN where the lane does not enter the child.
-template <bool UNIFORM_SIGN, bool FAST>
-__device__ __forceinline__ void pk_slab2(const PkLane &L, const i32x16 &lo, const i32x16 &hi, const int c0,
-	bool usx, bool usy, bool usz, bool live, float &pay0, float &pay1)
+// Slab test of children C0 and C0+1 for every lane; node rows in SGPRs (near rows first when the
+// packet's direction signs are uniform). Two children at a time so that the (bound - origin) * rcp
+// of rtk.c:458-463 maps onto v_pk_add_f32 / v_pk_mul_f32. Writes the per-lane entry distance, or
+// NaN where the lane does not enter the child.
+template <bool UNIFORM_SIGN, bool FAST, int C0>
+__device__ __forceinline__ void pk_slab2(const PkLane &L, const PkNode &n, bool live, float &pay0, float &pay1)
 {
-	f32x2 nx, fx, ny, fy, nz, fz;
-	const f32x2 bx0 = mk2(lo[c0], lo[c0 + 1]), bx1 = mk2(lo[4 + c0], lo[5 + c0]);
-	const f32x2 by0 = mk2(lo[8 + c0], lo[9 + c0]), by1 = mk2(lo[12 + c0], lo[13 + c0]);
-	const f32x2 bz0 = mk2(hi[c0], hi[c0 + 1]), bz1 = mk2(hi[4 + c0], hi[5 + c0]);
-	if (UNIFORM_SIGN) {
-		// near/far planes picked on the scalar side by the (wave-uniform) direction sign bits
-		nx = ((usx ? bx1 : bx0) - L.ox) * L.rdx; fx = ((usx ? bx0 : bx1) - L.ox) * L.rdx;
-		ny = ((usy ? by1 : by0) - L.oy) * L.rdy; fy = ((usy ? by0 : by1) - L.oy) * L.rdy;
-		nz = ((usz ? bz1 : bz0) - L.oz) * L.rdz; fz = ((usz ? bz0 : bz1) - L.oz) * L.rdz;
-	} else {
-		const f32x2 x0 = (bx0 - L.ox) * L.rdx, x1 = (bx1 - L.ox) * L.rdx;
-		const f32x2 y0 = (by0 - L.oy) * L.rdy, y1 = (by1 - L.oy) * L.rdy;
-		const f32x2 z0 = (bz0 - L.oz) * L.rdz, z1 = (bz1 - L.oz) * L.rdz;
-		nx = L.sx ? x1 : x0; fx = L.sx ? x0 : x1;
-		ny = L.sy ? y1 : y0; fy = L.sy ? y0 : y1;
-		nz = L.sz ? z1 : z0; fz = L.sz ? z0 : z1;
+	const f32x2 rx0 = mk2(n.nx[C0], n.nx[C0 + 1]), rx1 = mk2(n.fx[C0], n.fx[C0 + 1]);
+	const f32x2 ry0 = mk2(n.ny[C0], n.ny[C0 + 1]), ry1 = mk2(n.fy[C0], n.fy[C0 + 1]);
+	const f32x2 rz0 = mk2(n.nz[C0], n.nz[C0 + 1]), rz1 = mk2(n.fz[C0], n.fz[C0 + 1]);
+	f32x2 nx = (rx0 - L.ox) * L.rdx, fx = (rx1 - L.ox) * L.rdx;
+	f32x2 ny = (ry0 - L.oy) * L.rdy, fy = (ry1 - L.oy) * L.rdy;
+	f32x2 nz = (rz0 - L.oz) * L.rdz, fz = (rz1 - L.oz) * L.rdz;
+	if (!UNIFORM_SIGN) {
+		// rows were fetched as (min, max); pick near/far per lane
+		const f32x2 ax = nx, bx = fx, ay = ny, by = fy, az = nz, bz = fz;
+		nx = L.sx ? bx : ax; fx = L.sx ? ax : bx;
+		ny = L.sy ? by : ay; fy = L.sy ? ay : by;
+		nz = L.sz ? bz : az; fz = L.sz ? az : bz;
 	}
 	float tn0, tf0, tn1, tf1;
 	if (FAST) {
@@ -178,12 +189,46 @@ __device__ __forceinline__ void pk_slab2(const PkLane &L, const i32x16 &lo, cons
 		tn1 = sse_max(sse_max(nx.y, ny.y), sse_max(nz.y, L.tmin)); tf1 = sse_min(sse_min(fx.y, fy.y), sse_min(fz.y, L.t));
 	}
 	const float miss = __builtin_nanf("");
-	pay0 = (live && tn0 <= tf0 && (uint32_t)hi[8 + c0] != RTK_REF_NONE) ? tn0 : miss;
-	pay1 = (live && tn1 <= tf1 && (uint32_t)hi[9 + c0] != RTK_REF_NONE) ? tn1 : miss;
+	pay0 = (live && tn0 <= tf0 && (uint32_t)n.ch[C0] != RTK_REF_NONE) ? tn0 : miss;
+	pay1 = (live && tn1 <= tf1 && (uint32_t)n.ch[C0 + 1] != RTK_REF_NONE) ? tn1 : miss;
+}
+
+// All triangles of one leaf for the packet, in the reference's groups of four (rtk.c:212, 302-336).
+template <int KZ, bool COUNT>
+__device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, uint32_t slot0, uint32_t lane,
+	unsigned long long *counter, uint32_t &c_tris)
+{
+	i32x8 ta;
+	i32x4 tb;
+	s_load_tri(tris + (size_t)slot0 * 48u, ta, tb);
+	const uint32_t n = (uint32_t)tb[3];                                // leaf size rides in the first record
+	for (uint32_t g = 0; g < n; g += 4u) {
+		const uint32_t m = n - g < 4u ? n - g : 4u;
+		const bool force = m < 4u;                                     // padding slots make the whole group double (rtk.c:306)
+		const float sn_t = L.t, sn_u = L.u, sn_v = L.v;
+		const uint32_t sn_prim = L.prim;
+		bool zero_seen = false;
+		for (uint32_t j = 0; j < m; j++) {
+			if (g + j != 0u) s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
+			if (COUNT && live) c_tris++;
+			if (COUNT && lane == 0) atomicAdd(counter + 8, 1ull);
+			if (force) pk_triangle<true, KZ>(L, live, ta, tb);
+			else zero_seen |= pk_triangle<false, KZ>(L, live, ta, tb);
+		}
+		const bool redo = live && zero_seen;
+		if (__ballot(redo) != 0ull) {
+			// an exact zero in a full group: those lanes redo the group in double (rtk.c:302-336)
+			if (redo) { L.t = sn_t; L.u = sn_u; L.v = sn_v; L.prim = sn_prim; }
+			for (uint32_t j = 0; j < m; j++) {
+				s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
+				pk_triangle<true, KZ>(L, redo, ta, tb);
+			}
+		}
+	}
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK_THREADS) rtk_trace_packet_kernel(TraceParams p)
+__global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_packet_kernel(TraceParams p)
 {
 	__shared__ float s_t[TRACE_WAVES_PER_BLOCK][PK_LDS_STACK][64];
 
@@ -236,10 +281,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS) rtk_trace_packet_kernel(T
 		const bool wave_fast = __ballot(alive && special) == 0ull;
 		const unsigned long long bsx = __ballot(alive && L.sx), bsy = __ballot(alive && L.sy), bsz = __ballot(alive && L.sz);
 		const bool sign_uniform = (bsx == 0ull || bsx == m_alive) && (bsy == 0ull || bsy == m_alive) && (bsz == 0ull || bsz == m_alive);
-		const bool usx = bsx != 0ull, usy = bsy != 0ull, usz = bsz != 0ull;
+		const bool usx = sign_uniform && bsx != 0ull, usy = sign_uniform && bsy != 0ull, usz = sign_uniform && bsz != 0ull;
+		// byte offsets of the near / far plane rows inside a node (uniform signs), else (min, max)
+		const uint32_t onx = usx ? 16u : 0u, ofx = 16u - onx;
+		const uint32_t ony = 32u + (usy ? 16u : 0u), ofy = 80u - ony;
+		const uint32_t onz = 64u + (usz ? 16u : 0u), ofz = 144u - onz;
 		const unsigned long long bk0 = __ballot(alive && L.kz0), bk1 = __ballot(alive && L.kz1);
 		const bool kz_uniform = (bk0 == 0ull || bk0 == m_alive) && (bk1 == 0ull || bk1 == m_alive);
-		const uint32_t ukz = bk0 != 0ull ? 0u : (bk1 != 0ull ? 1u : 2u);
+		const uint32_t kzmode = !kz_uniform ? 3u : (bk0 != 0ull ? 0u : (bk1 != 0ull ? 1u : 2u));
 
 		uint32_t c_nodes = 0, c_leaves = 0, c_tris = 0, c_spills = 0;
 		uint32_t stack = 0;          // wave-uniform references, entry i in lane i
@@ -251,43 +300,46 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS) rtk_trace_packet_kernel(T
 			bool pop = false;
 			if ((int32_t)top >= 0) {
 				// ---------------------------------------------------- node (wave-uniform)
-				i32x16 lo, hi;
-				s_load_node(nodes + (size_t)top * 128u, lo, hi);
+				PkNode nd;
+				s_load_node(nodes + (size_t)top * 128u, onx, ofx, ony, ofy, onz, ofz, nd);
 				if (COUNT && live) c_nodes++;
 				if (COUNT && lane == 0) atomicAdd(p.counter + 7, 1ull);
 				// per lane: entry distance of each child, NaN = this lane does not enter it
 				float pay[4];
 				if (sign_uniform) {
-					if (wave_fast) { pk_slab2<true, true>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<true, true>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
-					else { pk_slab2<true, false>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<true, false>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
+					if (wave_fast) { pk_slab2<true, true, 0>(L, nd, live, pay[0], pay[1]); pk_slab2<true, true, 2>(L, nd, live, pay[2], pay[3]); }
+					else { pk_slab2<true, false, 0>(L, nd, live, pay[0], pay[1]); pk_slab2<true, false, 2>(L, nd, live, pay[2], pay[3]); }
 				} else {
-					if (wave_fast) { pk_slab2<false, true>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<false, true>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
-					else { pk_slab2<false, false>(L, lo, hi, 0, usx, usy, usz, live, pay[0], pay[1]); pk_slab2<false, false>(L, lo, hi, 2, usx, usy, usz, live, pay[2], pay[3]); }
+					if (wave_fast) { pk_slab2<false, true, 0>(L, nd, live, pay[0], pay[1]); pk_slab2<false, true, 2>(L, nd, live, pay[2], pay[3]); }
+					else { pk_slab2<false, false, 0>(L, nd, live, pay[0], pay[1]); pk_slab2<false, false, 2>(L, nd, live, pay[2], pay[3]); }
 				}
-				// wave-level: which children does anybody enter, and in which order (entry distance of
-				// the first live lane; a child nobody enters sorts last)
-				const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
-				int key[4];
-				uint32_t ref[4] = { (uint32_t)hi[8], (uint32_t)hi[9], (uint32_t)hi[10], (uint32_t)hi[11] };
-				uint32_t n_any = 0;
+				// wave-level: which children does anybody enter
+				const bool e0 = pay[0] == pay[0], e1 = pay[1] == pay[1], e2 = pay[2] == pay[2], e3 = pay[3] == pay[3];
+				const bool a0 = __ballot(e0) != 0ull, a1 = __ballot(e1) != 0ull, a2 = __ballot(e2) != 0ull, a3 = __ballot(e3) != 0ull;
+				const uint32_t n_any = (a0 ? 1u : 0u) + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
+				uint32_t ref[4] = { (uint32_t)nd.ch[0], (uint32_t)nd.ch[1], (uint32_t)nd.ch[2], (uint32_t)nd.ch[3] };
+				if (n_any == 0u) {
+					pop = true;
+				} else if (n_any == 1u) {
+					// one child for the whole packet: a lane enters it iff it enters anything
+					live = e0 || e1 || e2 || e3;
+					top = a0 ? ref[0] : (a1 ? ref[1] : (a2 ? ref[2] : ref[3]));
+				} else {
+					// order by the entry distance seen by the first live lane; its own misses (NaN) sort behind
+					// its hits, children nobody enters sort last. Keys per lane on the VALU, one readlane each.
+					const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
+					int key[4];
 #pragma unroll
-				for (int c = 0; c < 4; c++) {
-					const bool any = __ballot(pay[c] == pay[c]) != 0ull;
-					const float kf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay[c]), lead));
-					// the lead lane may itself miss this child (NaN): then order it behind its own hits
-					key[c] = any ? (kf == kf ? sort_key(kf) : 0x7ffffffe) : 0x7fffffff;
-					n_any += any ? 1u : 0u;
-				}
-				// sorting network; keys and references on the scalar side, the per-lane payload follows with
-				// wave-uniform select conditions
+					for (int c = 0; c < 4; c++) key[c] = __builtin_amdgcn_readlane(sort_key(pay[c]), lead);
+					key[0] = a0 ? key[0] : 0x7fffffff; key[1] = a1 ? key[1] : 0x7fffffff;
+					key[2] = a2 ? key[2] : 0x7fffffff; key[3] = a3 ? key[3] : 0x7fffffff;
+					// sorting network; keys and references on the scalar side, the per-lane payload follows with
+					// wave-uniform select conditions
 #define PK_CSWAP(a, b) { const bool s_ = key[b] < key[a]; const int ka_ = s_ ? key[b] : key[a], kb_ = s_ ? key[a] : key[b]; \
 	const uint32_t ra_ = s_ ? ref[b] : ref[a], rb_ = s_ ? ref[a] : ref[b]; const float pa_ = s_ ? pay[b] : pay[a], pb_ = s_ ? pay[a] : pay[b]; \
 	key[a] = ka_; key[b] = kb_; ref[a] = ra_; ref[b] = rb_; pay[a] = pa_; pay[b] = pb_; }
-				PK_CSWAP(0, 1) PK_CSWAP(2, 3) PK_CSWAP(0, 2) PK_CSWAP(1, 3) PK_CSWAP(1, 2)
+					PK_CSWAP(0, 1) PK_CSWAP(2, 3) PK_CSWAP(0, 2) PK_CSWAP(1, 3) PK_CSWAP(1, 2)
 #undef PK_CSWAP
-				if (n_any == 0u) {
-					pop = true;
-				} else {
 					// far children first so that the nearest is popped first (rtk.c:520-535)
 #pragma unroll
 					for (int i = 3; i >= 1; i--) {
@@ -304,34 +356,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS) rtk_trace_packet_kernel(T
 			} else {
 				// ---------------------------------------------------- leaf (wave-uniform)
 				const uint32_t slot0 = top & 0x7fffffffu;
-				i32x8 ta;
-				i32x4 tb;
-				s_load_tri(tris + (size_t)slot0 * 48u, ta, tb);
-				const uint32_t n = (uint32_t)tb[3];                                // leaf size rides in the first record
 				if (COUNT && live) c_leaves++;
-				for (uint32_t g = 0; g < n; g += 4u) {
-					const uint32_t m = n - g < 4u ? n - g : 4u;
-					const bool force = m < 4u;                                     // padding slots make the whole group double (rtk.c:306)
-					const float sn_t = L.t, sn_u = L.u, sn_v = L.v;
-					const uint32_t sn_prim = L.prim;
-					bool zero_seen = false;
-					for (uint32_t j = 0; j < m; j++) {
-						if (g + j != 0u) s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
-						if (COUNT && live) c_tris++;
-						if (COUNT && lane == 0) atomicAdd(p.counter + 8, 1ull);
-						if (force) pk_triangle<true>(L, live, kz_uniform, ukz, ta, tb);
-						else zero_seen |= pk_triangle<false>(L, live, kz_uniform, ukz, ta, tb);
-					}
-					const bool redo = live && zero_seen;
-					if (__ballot(redo) != 0ull) {
-						// an exact zero in a full group: those lanes redo the group in double (rtk.c:302-336)
-						if (redo) { L.t = sn_t; L.u = sn_u; L.v = sn_v; L.prim = sn_prim; }
-						for (uint32_t j = 0; j < m; j++) {
-							s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
-							pk_triangle<true>(L, redo, kz_uniform, ukz, ta, tb);
-						}
-					}
-				}
+				if (kzmode == 2u) pk_leaf<2, COUNT>(L, live, tris, slot0, lane, p.counter, c_tris);
+				else if (kzmode == 0u) pk_leaf<0, COUNT>(L, live, tris, slot0, lane, p.counter, c_tris);
+				else if (kzmode == 1u) pk_leaf<1, COUNT>(L, live, tris, slot0, lane, p.counter, c_tris);
+				else pk_leaf<3, COUNT>(L, live, tris, slot0, lane, p.counter, c_tris);
 				pop = true;
 			}
 			if (pop) {
