@@ -20,6 +20,7 @@
 #include "rtk_dev.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -383,8 +384,35 @@ __device__ __forceinline__ void tri_box(const DevTri *tris, uint32_t s, float mn
 }
 
 // One thread per sorted triangle walks towards the root; the second thread to arrive at a
-// node (agent-scope acq_rel counter) owns it. The acq_rel arrival makes the first
-// arriver's BinNode visible to the second whichever CUs/XCDs they ran on.
+// node owns it. The hand-off of the first arriver's 32-byte record has to cross CUs and XCDs
+// (per-CU L1 and per-XCD L2 are not coherent with each other). An acq_rel arrival counter does
+// that with a cache write-back + invalidate per wave per level (39 ms of a 10M-triangle build);
+// instead the record itself travels as four 8-byte device-scope atomics, which execute at the
+// memory side and are therefore coherent everywhere, and the arrival counter stays relaxed.
+__device__ __forceinline__ void bin_store(BinNode *dst, const BinNode &v)
+{
+	unsigned long long *d = reinterpret_cast<unsigned long long *>(dst);
+	const unsigned long long *sv = reinterpret_cast<const unsigned long long *>(&v);
+#pragma unroll
+	for (int k = 0; k < 4; k++) (void)__hip_atomic_exchange(d + k, sv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ BinNode bin_load(BinNode *src)
+{
+	BinNode v;
+	unsigned long long *d = reinterpret_cast<unsigned long long *>(src);
+	unsigned long long *dv = reinterpret_cast<unsigned long long *>(&v);
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		// a real read-modify-write (hipcc folds fetch_add(p, 0) into an sc1 load): compare-and-swap of a
+		// value with itself returns the memory-side copy and never changes it
+		unsigned long long expect = ~0ull;
+		(void)__hip_atomic_compare_exchange_strong(d + k, &expect, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		dv[k] = expect;
+	}
+	return v;
+}
+
 __global__ void k_refit(const DevTri *tris, int n, const int *left, const int *right, const int *parent_inner,
 	const int *parent_leaf, uint32_t *arrive, BinNode *bin, BuildParams bp)
 {
@@ -392,7 +420,9 @@ __global__ void k_refit(const DevTri *tris, int n, const int *left, const int *r
 	if (i >= n) return;
 	int node = parent_leaf[i];
 	while (node >= 0) {
-		const uint32_t old = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		// every record this thread published is complete at the memory side before it announces itself
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const uint32_t old = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (old == 0u) return;
 		float mn[3], mx[3], cost = 0.0f;
 		uint32_t cnt = 0;
@@ -405,7 +435,7 @@ __global__ void k_refit(const DevTri *tris, int n, const int *left, const int *r
 				ccnt = 1u;
 				ccost = bp.cost_tri * half_area(cmn, cmx);
 			} else {
-				const BinNode b = bin[c];
+				const BinNode b = bin_load(&bin[c]);
 				cmn[0] = b.mn[0]; cmn[1] = b.mn[1]; cmn[2] = b.mn[2];
 				cmx[0] = b.mx[0]; cmx[1] = b.mx[1]; cmx[2] = b.mx[2];
 				ccnt = b.cnt_flag & 0x7fffffffu;
@@ -424,7 +454,7 @@ __global__ void k_refit(const DevTri *tris, int n, const int *left, const int *r
 		out.mx[0] = mx[0]; out.mx[1] = mx[1]; out.mx[2] = mx[2];
 		out.cnt_flag = cnt | (leaf <= split ? 0x80000000u : 0u);
 		out.cost = fminf(leaf, split);
-		bin[node] = out;
+		bin_store(&bin[node], out);
 		node = parent_inner[node];
 	}
 }
@@ -585,6 +615,21 @@ void decode_mesh_on_host(const rtk_mesh *m, float *pos9, uint32_t *vidx3)
 	}
 }
 
+// Caller memory that is already device memory (hipMalloc) is read in place by the ingest kernel.
+bool is_device_ptr(const void *p)
+{
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return attr.type == hipMemoryTypeDevice;
+}
+
+// Host memory -> device. A plain hipMemcpy (the runtime's own pinned staging) measured faster on the
+// GPU box than a hand-rolled double-buffered copy (19 vs 25 ms per 10M-triangle build, steady state).
+hipError_t upload_staged(void *dst, const void *src, size_t bytes)
+{
+	return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+
 #define BUILD_CHECK(expr)                                                                               \
 	do {                                                                                                \
 		hipError_t e_ = (expr);                                                                         \
@@ -648,6 +693,15 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	const uint32_t n = (uint32_t)n64;
 	if (desc->log_fn) desc->log_fn(desc->log_user, nullptr, "rtk_amd: device LBVH build");
 	const auto t_begin = std::chrono::steady_clock::now();
+	const bool timing = getenv("RTK_AMD_BUILD_TIMING") != nullptr;
+	auto t_last = t_begin;
+	auto stage = [&](const char *name) {
+		if (!timing) return;
+		(void)hipDeviceSynchronize();
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "rtk_amd build: %-10s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 
 	int device = 0;
 	hipDeviceProp_t prop;
@@ -657,7 +711,9 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	// ---- 1 ingest ------------------------------------------------------------------
 	DevBuf<float> in_pos;
 	DevBuf<uint32_t> in_vidx;
+	stage("props");
 	if (!in_pos.alloc(9 * (size_t)n) || !in_vidx.alloc(3 * (size_t)n)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+	stage("alloc-in");
 	std::vector<float> tiny_pos;
 	std::vector<uint32_t> tiny_vidx;
 	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
@@ -681,36 +737,52 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		int idx_kind = 0;
 		size_t istride = 0;
 		uint64_t max_vertex = 3ull * nt - 1;
-		DevBuf<char> d_idx;
+		DevBuf<char> d_idx, d_pos;
+		const char *idx_ptr = nullptr, *pos_ptr = nullptr;
+		const bool pos_on_device = is_device_ptr(m->position.data);
 		if (m->index.data) {
 			const bool u16 = m->index.type == RTK_TYPE_U16;
 			if (!u16 && m->index.type != RTK_TYPE_U32 && m->index.type != RTK_TYPE_DEFAULT) { rtk_set_error("rtk_dev_scene_build: bad index type"); return nullptr; }
 			idx_kind = u16 ? 1 : 2;
 			istride = m->index.stride ? m->index.stride : (u16 ? 6 : 12);
-			max_vertex = 0;
-			for (size_t i = 0; i < nt; i++) {
-				const char *p = (const char *)m->index.data + i * istride;
-				for (int c = 0; c < 3; c++) {
-					const uint64_t v = u16 ? ((const uint16_t *)p)[c] : ((const uint32_t *)p)[c];
-					if (v > max_vertex) max_vertex = v;
+			if (is_device_ptr(m->index.data)) {
+				if (!pos_on_device) { rtk_set_error("rtk_dev_scene_build: mesh %zu has device indices but host positions", mi); return nullptr; }
+				idx_ptr = (const char *)m->index.data;
+			} else {
+				if (!pos_on_device) {
+					max_vertex = 0;
+					for (size_t i = 0; i < nt; i++) {
+						const char *p = (const char *)m->index.data + i * istride;
+						for (int c = 0; c < 3; c++) {
+							const uint64_t v = u16 ? ((const uint16_t *)p)[c] : ((const uint32_t *)p)[c];
+							if (v > max_vertex) max_vertex = v;
+						}
+					}
 				}
+				const size_t ibytes = (nt - 1) * istride + (u16 ? 6 : 12);
+				if (!d_idx.alloc(ibytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+				BUILD_CHECK(upload_staged(d_idx.p, m->index.data, ibytes));
+				idx_ptr = d_idx.p;
 			}
-			const size_t ibytes = (nt - 1) * istride + (u16 ? 6 : 12);
-			if (!d_idx.alloc(ibytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
-			BUILD_CHECK(hipMemcpy(d_idx.p, m->index.data, ibytes, hipMemcpyHostToDevice));
 		}
-		const size_t pbytes = (size_t)max_vertex * pstride + (f64 ? 24 : 12);
-		DevBuf<char> d_pos;
-		if (!d_pos.alloc(pbytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
-		BUILD_CHECK(hipMemcpy(d_pos.p, m->position.data, pbytes, hipMemcpyHostToDevice));
+		if (pos_on_device) {
+			pos_ptr = (const char *)m->position.data;
+		} else {
+			const size_t pbytes = (size_t)max_vertex * pstride + (f64 ? 24 : 12);
+			if (!d_pos.alloc(pbytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+			BUILD_CHECK(upload_staged(d_pos.p, m->position.data, pbytes));
+			pos_ptr = d_pos.p;
+		}
+		stage("upload");
 		const unsigned iblocks = (unsigned)((nt + 255) / 256);
-		if (idx_kind == 0) launch_ingest<0>(f64, iblocks, d_pos.p, pstride, d_idx.p, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
-		else if (idx_kind == 1) launch_ingest<1>(f64, iblocks, d_pos.p, pstride, d_idx.p, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
-		else launch_ingest<2>(f64, iblocks, d_pos.p, pstride, d_idx.p, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
+		if (idx_kind == 0) launch_ingest<0>(f64, iblocks, pos_ptr, pstride, idx_ptr, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
+		else if (idx_kind == 1) launch_ingest<1>(f64, iblocks, pos_ptr, pstride, idx_ptr, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
+		else launch_ingest<2>(f64, iblocks, pos_ptr, pstride, idx_ptr, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
 		BUILD_CHECK(hipGetLastError());
 		BUILD_CHECK(hipDeviceSynchronize());   // d_pos/d_idx are released at scope end
 	}
 	if (n < 2) return build_tiny(desc, mesh_base, tiny_pos, tiny_vidx);
+	stage("ingest");
 
 	BuildParams bp;
 	bp.cost_tri = env_float("RTK_AMD_SAH_CT", 1.0f);
@@ -733,6 +805,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		BUILD_CHECK(hipGetLastError());
 	}
 
+	stage("morton");
 	// ---- 4 sort ------------------------------------------------------------------------
 	{
 		const uint32_t num_units = (n + SORT_WAVE_ITEMS - 1u) / SORT_WAVE_ITEMS;
@@ -752,6 +825,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		BUILD_CHECK(hipDeviceSynchronize());
 	}
 
+	stage("sort");
 	// ---- 5 emit: final triangle records in Morton order ----------------------------------
 	rtk_dev_scene *ds = new rtk_dev_scene();
 	ds->device = device;
@@ -784,6 +858,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
 	}
 
+	stage("emit");
 	// ---- 6 karras, 7 refit ------------------------------------------------------------------
 	DevBuf<int> d_left, d_right, d_parent_inner, d_parent_leaf;
 	DevBuf<uint32_t> d_first, d_last, d_arrive;
@@ -797,6 +872,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		d_parent_leaf.p, d_arrive.p, d_bin.p, bp);
 	if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("karras/refit");
 
+	stage("tree+refit");
 	// ---- 8 collapse, one launch per level of the 4-wide tree -----------------------------------
 	DevBuf<DevNode> d_nodes_tmp;       // worst case one wide node per binary inner node
 	DevBuf<WideJob> jobs_a, jobs_b;
@@ -821,6 +897,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		if (depth > 4096) return fail("collapse did not terminate");
 	}
 
+	stage("collapse");
 	// shrink the node array to what was used
 	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
 	if (!d_nodes) return fail("out of device memory");
@@ -839,6 +916,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	ds->view.num_prims = n;
 	ds->max_depth = depth;
 	ds->stack_entries = 3u * depth + 1u;
+	stage("finish");
 	ds->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 	return ds;
 }

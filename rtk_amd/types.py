@@ -74,15 +74,36 @@ class MeshSet:
         arr = (Mesh * max(1, len(meshes)))()
         self.num_triangles = 0
         for i, m in enumerate(meshes):
-            pos = np.ascontiguousarray(m["positions"])
-            assert pos.dtype in (np.float32, np.float64) and pos.ndim == 2 and pos.shape[1] == 3
-            self._keep.append(pos)
             me = arr[i]
-            me.position.data = pos.ctypes.data
-            me.position.stride = 0
-            me.position.type = RTK_TYPE_F64 if pos.dtype == np.float64 else RTK_TYPE_F32
+            pos = m["positions"]
+            if hasattr(pos, "data_ptr"):
+                # a torch tensor; if it lives on the GPU the builder reads it in place (no PCIe copy)
+                assert pos.is_contiguous() and pos.dim() == 2 and pos.shape[1] == 3
+                f64 = str(pos.dtype) == "torch.float64"
+                assert f64 or str(pos.dtype) == "torch.float32"
+                self._keep.append(pos)
+                me.position.data = pos.data_ptr()
+                me.position.stride = 0
+                me.position.type = RTK_TYPE_F64 if f64 else RTK_TYPE_F32
+                assert m.get("indices") is None or hasattr(m["indices"], "data_ptr") or True
+            else:
+                pos = np.ascontiguousarray(pos)
+                assert pos.dtype in (np.float32, np.float64) and pos.ndim == 2 and pos.shape[1] == 3
+                self._keep.append(pos)
+                me.position.data = pos.ctypes.data
+                me.position.stride = 0
+                me.position.type = RTK_TYPE_F64 if pos.dtype == np.float64 else RTK_TYPE_F32
             idx = m.get("indices")
-            if idx is not None:
+            if idx is not None and hasattr(idx, "data_ptr"):
+                assert idx.is_contiguous() and idx.dim() == 2 and idx.shape[1] == 3
+                u16 = str(idx.dtype) in ("torch.uint16", "torch.int16")
+                assert u16 or str(idx.dtype) in ("torch.int32", "torch.uint32")
+                self._keep.append(idx)
+                me.index.data = idx.data_ptr()
+                me.index.stride = 0
+                me.index.type = RTK_TYPE_U16 if u16 else RTK_TYPE_U32
+                me.num_triangles = idx.shape[0]
+            elif idx is not None:
                 idx = np.ascontiguousarray(idx)
                 assert idx.dtype in (np.uint16, np.uint32) and idx.ndim == 2 and idx.shape[1] == 3
                 self._keep.append(idx)

@@ -196,3 +196,20 @@ def test_config5_device_build_any_hit_vs_golden(api, golden_dir):
     big = synth.rays_shadow(1 << 20)
     rec = ds.trace(big, full=False)
     assert (ds.trace_any(big) == (rec["prim"] != 0xFFFFFFFF)).all()
+
+
+def test_device_resident_mesh_is_read_in_place(api, oracle):
+    """Positions (and indices) that already live in HBM: same scene, same hits as host buffers."""
+    import torch
+    tris = synth.scene_for_config(1)
+    ds_host = api.DeviceScene.build([dict(positions=tris)])
+    ds_dev = api.DeviceScene.build([dict(positions=torch.from_numpy(tris).cuda())])
+    rays = synth.rays_config1(8192)
+    assert ds_host.trace(rays, full=False).tobytes() == ds_dev.trace(rays, full=False).tobytes()
+    idx = np.arange(30000, dtype=np.int32).reshape(-1, 3)[::-1].copy()
+    ds_idx = api.DeviceScene.build([dict(positions=torch.from_numpy(tris).cuda(), indices=torch.from_numpy(idx).cuda())])
+    rec = ds_idx.trace(rays, full=False)
+    base = ds_host.trace(rays, full=False)
+    hit = base["prim"] != 0xFFFFFFFF
+    assert ((rec["prim"] != 0xFFFFFFFF) == hit).all()
+    assert (rec["prim"][hit] == 9999 - base["prim"][hit]).all() and (rec["t"][hit] == base["t"][hit]).all()
