@@ -105,6 +105,9 @@ void rtk_dev_scene_free(rtk_dev_scene *ds);
 int rtk_dev_scene_get_info(const rtk_dev_scene *ds, rtk_dev_scene_info *info);
 /* mesh_base[0..num_meshes] (prefix sums of per-mesh triangle counts) */
 int rtk_dev_scene_mesh_base(const rtk_dev_scene *ds, uint64_t *out, size_t capacity);
+/* out[slot] = global primitive id of the triangle stored at that slot (device order: leaf by leaf;
+ * Morton order for device-built scenes). capacity in elements; returns the triangle count or < 0. */
+long long rtk_dev_scene_primitive_order(const rtk_dev_scene *ds, uint32_t *out, size_t capacity);
 size_t rtk_dev_scene_export_size(const rtk_dev_scene *ds);
 rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *ds, void *buffer, size_t size);
 

@@ -54,7 +54,7 @@ RTK_H_SYMBOLS = ["rtk_start_build", "rtk_run_task", "rtk_get_build_size", "rtk_f
                  "rtk_finish_build", "rtk_build_scene", "rtk_free_scene", "rtk_trace_ray", "rtk_trace_ray_filter"]
 RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_device",
                      "rtk_dev_scene_upload", "rtk_dev_scene_build", "rtk_dev_scene_free", "rtk_dev_scene_get_info",
-                     "rtk_dev_scene_mesh_base", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
+                     "rtk_dev_scene_mesh_base", "rtk_dev_scene_primitive_order", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
                      "rtk_dev_trace_rays", "rtk_dev_trace_rays_any", "rtk_dev_expand_hits",
                      "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_trace_rays", "rtk_amd_forget_scene"]
 
@@ -83,6 +83,8 @@ def lib():
     L.rtk_dev_scene_free.argtypes = [C.c_void_p]
     L.rtk_dev_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
     L.rtk_dev_scene_mesh_base.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rtk_dev_scene_primitive_order.restype = C.c_longlong
+    L.rtk_dev_scene_primitive_order.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.rtk_dev_scene_export_size.restype = C.c_size_t
     L.rtk_dev_scene_export_size.argtypes = [C.c_void_p]
     L.rtk_dev_scene_export.restype = C.c_void_p
@@ -204,6 +206,14 @@ class DeviceScene:
         if rc < 0:
             raise RtkError(last_error())
         return out
+
+    def primitive_order(self):
+        n = self.info()["num_triangles"]
+        out = np.zeros(max(n, 1), np.uint32)
+        rc = lib().rtk_dev_scene_primitive_order(self.handle, out.ctypes.data, out.size)
+        if rc < 0:
+            raise RtkError(last_error())
+        return out[:n]
 
     def export_blob(self):
         size = lib().rtk_dev_scene_export_size(self.handle)

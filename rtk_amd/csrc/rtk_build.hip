@@ -32,7 +32,7 @@ void rtk_cache_adopt(const rtk_scene *scene, rtk_dev_scene *ds);
 
 namespace {
 
-#define SORT_WAVE_ITEMS 1024u     // keys handled by one wave per pass (16 chunks of 64)
+#define SORT_TILE 4096u           // keys handled by one workgroup per pass (4 waves x 16 chunks of 64)
 #define SORT_BLOCK 256
 
 struct BinNode {                  // 32 B, written by refit
@@ -178,28 +178,24 @@ __global__ void k_morton(const float *in_pos, uint32_t n, const uint32_t *bounds
 }
 
 // ---------------------------------------------------------------------------------- 4 radix sort
-// Unit of work = one wave = SORT_WAVE_ITEMS consecutive keys. hist is digit-major:
+// Unit of work = one workgroup = SORT_TILE consecutive keys (4 waves x 1024). hist is digit-major:
 // hist[digit * num_units + unit], so one exclusive scan over the whole array yields, for
 // every (digit, unit), the first output position of that unit's keys with that digit.
 
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort_hist(const unsigned long long *keys, uint32_t n, uint32_t shift,
 	uint32_t num_units, uint32_t *hist)
 {
-	__shared__ uint32_t s_h[SORT_BLOCK / 64][256];
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t unit = blockIdx.x * (SORT_BLOCK / 64) + wave;
-	for (int j = 0; j < 4; j++) s_h[wave][lane + 64 * j] = 0;
+	__shared__ uint32_t s_h[256];
+	const uint32_t unit = blockIdx.x;
+	s_h[threadIdx.x] = 0;
 	__syncthreads();
-	if (unit < num_units) {
-		const size_t base = (size_t)unit * SORT_WAVE_ITEMS;
-		for (uint32_t c = 0; c < SORT_WAVE_ITEMS / 64u; c++) {
-			const size_t i = base + c * 64u + lane;
-			if (i < n) atomicAdd(&s_h[wave][(uint32_t)(keys[i] >> shift) & 255u], 1u);
-		}
+	const size_t base = (size_t)unit * SORT_TILE;
+	for (uint32_t c = 0; c < SORT_TILE / SORT_BLOCK; c++) {
+		const size_t i = base + (size_t)c * SORT_BLOCK + threadIdx.x;     // coalesced 2 KB per step
+		if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
 	}
 	__syncthreads();
-	if (unit < num_units)
-		for (int j = 0; j < 4; j++) hist[(size_t)(lane + 64 * j) * num_units + unit] = s_h[wave][lane + 64 * j];
+	hist[(size_t)threadIdx.x * num_units + unit] = s_h[threadIdx.x];
 }
 
 // exclusive scan of a uint32 array, three launches (block sums -> scan of sums -> add)
@@ -260,23 +256,44 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t *data, size_t 
 	for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) data[base + k] += add;
 }
 
+// Scatter pass with an LDS-staged tile. Each wave ranks its 1024 keys in order (16 chunks of 64;
+// the rank of a key inside a chunk comes from 8 ballots, the running per-digit counts of the wave
+// live in LDS), the four waves' counts are combined into tile-wide digit offsets, the (key, value)
+// pairs are written to their SORTED position inside the tile in LDS, and the tile is then streamed
+// out in that order: neighbouring threads hold neighbouring keys of the same digit, so the global
+// stores form contiguous runs (16 keys on average for random digits) instead of one store per key.
+// Stable: tile order = wave order = chunk order = lane order.
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long long *keys_in, const uint32_t *vals_in, uint32_t n,
 	uint32_t shift, uint32_t num_units, const uint32_t *hist, unsigned long long *keys_out, uint32_t *vals_out)
 {
-	__shared__ uint32_t s_pos[SORT_BLOCK / 64][256];
+	__shared__ unsigned long long s_key[SORT_TILE];          // 32 KB
+	__shared__ uint32_t s_val[SORT_TILE];                    // 16 KB
+	__shared__ uint32_t s_cnt[SORT_BLOCK / 64][256];         // per wave: running count, then prefix over earlier waves
+	__shared__ uint32_t s_start[256];                        // first tile position of each digit
+	__shared__ uint32_t s_global[256];                       // first output position of this tile's keys of each digit
+	__shared__ uint32_t s_wsum[SORT_BLOCK / 64];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t unit = blockIdx.x * (SORT_BLOCK / 64) + wave;
-	if (unit >= num_units) return;          // whole wave leaves together; no block barrier below
-	for (int j = 0; j < 4; j++) s_pos[wave][lane + 64 * j] = hist[(size_t)(lane + 64 * j) * num_units + unit];
-	const size_t base = (size_t)unit * SORT_WAVE_ITEMS;
+	const uint32_t unit = blockIdx.x;
+	const size_t tile_base = (size_t)unit * SORT_TILE;
+	const uint32_t tile_n = (uint32_t)((size_t)n - tile_base < SORT_TILE ? (size_t)n - tile_base : SORT_TILE);
+
+	for (int j = 0; j < 4; j++) s_cnt[wave][lane + 64 * j] = 0;
+	s_global[threadIdx.x] = hist[(size_t)threadIdx.x * num_units + unit];
+	__syncthreads();
+
+	// ---- phase 1: rank every key among the keys of its digit inside its wave
+	constexpr uint32_t CHUNKS = SORT_TILE / SORT_BLOCK;      // 16 chunks of 64 keys per wave
+	unsigned long long key[CHUNKS];
+	uint32_t val[CHUNKS], rnk[CHUNKS];
 	const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64u - lane));
-	for (uint32_t c = 0; c < SORT_WAVE_ITEMS / 64u; c++) {
-		const size_t i = base + c * 64u + lane;
+	const size_t wave_base = tile_base + (size_t)wave * (SORT_TILE / (SORT_BLOCK / 64));
+#pragma unroll
+	for (uint32_t c = 0; c < CHUNKS; c++) {
+		const size_t i = wave_base + (size_t)c * 64u + lane;
 		const bool valid = i < n;
-		const unsigned long long key = valid ? keys_in[i] : 0ull;
-		const uint32_t val = valid ? vals_in[i] : 0u;
-		const uint32_t d = (uint32_t)(key >> shift) & 255u;
-		// lanes of this chunk holding the same digit (8 ballots)
+		key[c] = valid ? keys_in[i] : ~0ull;
+		val[c] = valid ? vals_in[i] : 0u;
+		const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
 		unsigned long long same = __ballot(valid);
 #pragma unroll
 		for (int b = 0; b < 8; b++) {
@@ -284,14 +301,52 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 			const unsigned long long vote = __ballot(bit);
 			same &= bit ? vote : ~vote;
 		}
+		rnk[c] = 0;
 		if (valid) {
-			const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
-			const uint32_t start = s_pos[wave][d];                 // all lanes read before any leader writes (wave program order)
-			const uint32_t dst = start + rank;
-			keys_out[dst] = key;
-			vals_out[dst] = val;
-			if (rank == 0u) s_pos[wave][d] = start + (uint32_t)__popcll(same);
+			const uint32_t r = (uint32_t)__popcll(same & lt_mask);
+			const uint32_t before = s_cnt[wave][d];            // every lane reads before any leader writes (wave program order)
+			rnk[c] = before + r;
+			if (r == 0u) s_cnt[wave][d] = before + (uint32_t)__popcll(same);
 		}
+	}
+	__syncthreads();
+
+	// ---- phase 2: tile-wide digit offsets. Thread d owns digit d.
+	{
+		const uint32_t d = threadIdx.x;
+		uint32_t run = 0;
+		for (uint32_t w = 0; w < SORT_BLOCK / 64; w++) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = run; run += c; }
+		// exclusive scan of the 256 digit totals
+		uint32_t inc = run;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+		if (lane == 63u) s_wsum[wave] = inc;
+		__syncthreads();
+		uint32_t off = 0;
+		for (uint32_t w = 0; w < wave; w++) off += s_wsum[w];
+		s_start[d] = off + inc - run;
+	}
+	__syncthreads();
+
+	// ---- phase 3: stage the tile in sorted order
+#pragma unroll
+	for (uint32_t c = 0; c < CHUNKS; c++) {
+		const size_t i = wave_base + (size_t)c * 64u + lane;
+		if (i < n) {
+			const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+			const uint32_t pos = s_start[d] + s_cnt[wave][d] + rnk[c];
+			s_key[pos] = key[c];
+			s_val[pos] = val[c];
+		}
+	}
+	__syncthreads();
+
+	// ---- phase 4: stream the tile out; runs of one digit are contiguous in LDS and in HBM
+	for (uint32_t i = threadIdx.x; i < tile_n; i += SORT_BLOCK) {
+		const unsigned long long k = s_key[i];
+		const uint32_t d = (uint32_t)(k >> shift) & 255u;
+		const uint32_t dst = s_global[d] + (i - s_start[d]);
+		keys_out[dst] = k;
+		vals_out[dst] = s_val[i];
 	}
 }
 
@@ -808,8 +863,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	stage("morton");
 	// ---- 4 sort ------------------------------------------------------------------------
 	{
-		const uint32_t num_units = (n + SORT_WAVE_ITEMS - 1u) / SORT_WAVE_ITEMS;
-		const unsigned blocks = (num_units + (SORT_BLOCK / 64) - 1) / (SORT_BLOCK / 64);
+		const uint32_t num_units = (n + SORT_TILE - 1u) / SORT_TILE;
+		const unsigned blocks = num_units;
 		DevBuf<uint32_t> hist;
 		if (!hist.alloc(256 * (size_t)num_units)) { rtk_set_error("device build: out of device memory"); return nullptr; }
 		unsigned long long *kin = keys_a.p, *kout = keys_b.p;

@@ -83,6 +83,18 @@ extern "C" int rtk_dev_scene_mesh_base(const rtk_dev_scene *ds, uint64_t *out, s
 	return (int)ds->mesh_base.size();
 }
 
+extern "C" long long rtk_dev_scene_primitive_order(const rtk_dev_scene *ds, uint32_t *out, size_t capacity)
+{
+	if (!ds || !out || capacity < ds->view.num_tris) { rtk_set_error("rtk_dev_scene_primitive_order: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
+	if (ds->view.num_tris == 0) return 0;
+	// DevTri.prim is the 4th dword of each 48-byte record
+	if (hipMemcpy2D(out, 4, reinterpret_cast<const char *>(ds->view.tris) + 12, sizeof(DevTri), 4, ds->view.num_tris, hipMemcpyDeviceToHost) != hipSuccess) {
+		rtk_set_error("rtk_dev_scene_primitive_order: copy failed: %s", hipGetErrorString(hipGetLastError()));
+		return RTK_AMD_ERR_HIP;
+	}
+	return (long long)ds->view.num_tris;
+}
+
 // ---------------------------------------------------------------------------- batches
 
 extern "C" int rtk_dev_trace_rays(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,

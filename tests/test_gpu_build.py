@@ -213,3 +213,38 @@ def test_device_resident_mesh_is_read_in_place(api, oracle):
     hit = base["prim"] != 0xFFFFFFFF
     assert ((rec["prim"] != 0xFFFFFFFF) == hit).all()
     assert (rec["prim"][hit] == 9999 - base["prim"][hit]).all() and (rec["t"][hit] == base["t"][hit]).all()
+
+
+def _morton_keys(tris):
+    """63-bit Morton keys exactly as rtk_build.hip's k_bounds/k_morton compute them (float32 ops)."""
+    t = tris.reshape(-1, 3, 3)
+    c2 = (t.min(axis=1) + t.max(axis=1)).astype(np.float32)
+    lo, hi = c2.min(axis=0), c2.max(axis=0)
+    ext = (hi - lo).astype(np.float32)
+    x = np.where(ext > 0, (c2 - lo) / np.where(ext > 0, ext, 1), 0).astype(np.float32)
+    x = np.clip(x, 0, 1)
+    q = np.minimum((x * np.float32(2097152.0)).astype(np.uint64), 2097151)
+
+    def spread(v):
+        v = v & np.uint64(0x1fffff)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+    return (spread(q[:, 0]) << np.uint64(2)) | (spread(q[:, 1]) << np.uint64(1)) | spread(q[:, 2])
+
+
+@pytest.mark.parametrize("n", [1000, 4096, 4097, 70001, 1_000_000])
+def test_radix_sort_leaves_triangles_in_morton_order(api, n):
+    """The LDS-staged LSD radix sort: device triangle order is a permutation, sorted by Morton key,
+    and stable (equal keys keep input order)."""
+    tris = synth.triangle_soup(n, 0.02, seed=11)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    order = ds.primitive_order()
+    assert len(order) == n and (np.sort(order) == np.arange(n)).all()
+    keys = _morton_keys(tris)[order]
+    assert (keys[1:] >= keys[:-1]).all()
+    same = keys[1:] == keys[:-1]
+    assert (order[1:][same] > order[:-1][same]).all()
