@@ -71,6 +71,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     api.lib().rtk_amd_set_device(local_rank)
     if world > 1:
@@ -136,28 +137,44 @@ def main():
         metric = "Mrays/sec (any-hit shadow) on 10M-tri scene"
     d_rays = api.to_device(rays)
     out_bytes = 1 if shadow else HIT_BYTES
-    d_out = torch.empty(n * out_bytes, dtype=torch.uint8, device="cuda")
+    # two output buffers: with N > 1 the gather of step k overlaps the trace of step k+1
+    d_outs = [torch.empty(n * out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
     sizes = [n * out_bytes] * world
+    gather = world > 1 and not args.no_gather
+    gathered = [torch.empty(sum(sizes), dtype=torch.uint8, device="cuda") if (gather and rank == 0) else None for _ in d_outs]
+    pending = [[] for _ in d_outs]
 
-    def trace():
+    def trace(buf):
         if shadow:
-            ds.trace_any_device(d_rays, n, d_out, opts)
+            ds.trace_any_device(d_rays, n, buf, opts)
         else:
-            ds.trace_device(d_rays, n, d_out, opts)
+            ds.trace_device(d_rays, n, buf, opts)
 
-    def step():
-        trace()
-        if world > 1 and not args.no_gather:
-            return shard.gather_records(d_out, sizes, dst=0)
-        return d_out
+    def step(k, ev=None):
+        b = k % len(d_outs)
+        shard.gather_records_wait(pending[b])       # this buffer's previous gather has drained
+        pending[b] = []
+        if ev:
+            ev[0].record()                          # same stream the kernel is launched on
+        trace(d_outs[b])
+        if ev:
+            ev[1].record()
+        if gather:
+            _, pending[b] = shard.gather_records_start(d_outs[b], sizes, dst=0, out=gathered[b])
+
+    def drain():
+        for b in range(len(d_outs)):
+            shard.gather_records_wait(pending[b])
+            pending[b] = []
 
     # ---- algorithmic bytes from the counting build (not timed) ----------------------------
     _, ctr = ds.trace_any_counted(rays, opts) if shadow else ds.trace_counted(rays, opts)
     alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
     torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -167,11 +184,8 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t_start = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()                       # same stream the kernel is launched on
-        trace()
-        ev[k][1].record()
-        if world > 1 and not args.no_gather:
-            shard.gather_records(d_out, sizes, dst=0)
+        step(k, ev[k])
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,6 +197,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    d_out = d_outs[(args.steps - 1) % len(d_outs)] if args.steps else d_outs[0]
 
     # ---- the result that was timed ---------------------------------------------------------
     if shadow:
@@ -233,7 +248,7 @@ def main():
                    "bvh_build_ms_device_resident_mesh": round(build_ms_device_mesh, 2) if build_ms_device_mesh else None,
                    "bvh_build_mtris_s_device_resident_mesh": round(cfg["num_tris"] / build_ms_device_mesh / 1e3, 1) if build_ms_device_mesh else None,
                    "hit_fraction": round(hit_frac, 4),
-                   "gather": bool(world > 1 and not args.no_gather), "launch": "static" if args.static else "persistent",
+                   "gather": ("records to rank 0 over RCCL, overlapped with the next step's trace" if gather else None), "launch": "static" if args.static else "persistent",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

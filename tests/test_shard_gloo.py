@@ -56,3 +56,40 @@ def test_gather_records_two_ranks(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), 1001, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def _pipelined_worker(rank, world, port, n, steps, out_path):
+    """bench.py's N>1 step loop: two output buffers, gather of step k in flight while step k+1 'traces'."""
+    sys.path.insert(0, ROOT)
+    from rtk_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [n * 16] * world
+    bufs = [torch.empty(n * 16, dtype=torch.uint8) for _ in range(2)]
+    gathered = [torch.empty(sum(sizes), dtype=torch.uint8) if rank == 0 else None for _ in range(2)]
+    pending = [[], []]
+    ok = True
+    for k in range(steps):
+        b = k % 2
+        shard.gather_records_wait(pending[b])
+        if rank == 0 and k >= 2:      # the gather that just drained belongs to step k-2
+            want = torch.cat([torch.full((n * 16,), (r * 7 + (k - 2)) % 251, dtype=torch.uint8) for r in range(world)])
+            ok = ok and bool((gathered[b] == want).all())
+        bufs[b].fill_((rank * 7 + k) % 251)          # "trace" of step k on this rank
+        _, pending[b] = shard.gather_records_start(bufs[b], sizes, dst=0, out=gathered[b])
+    for b in range(2):
+        shard.gather_records_wait(pending[b])
+    dist.barrier()
+    if rank == 0:
+        for k in (steps - 2, steps - 1):
+            want = torch.cat([torch.full((n * 16,), (r * 7 + k) % 251, dtype=torch.uint8) for r in range(world)])
+            ok = ok and bool((gathered[k % 2] == want).all())
+        open(out_path, "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_two_ranks(tmp_path):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), 257, 6, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
