@@ -182,3 +182,42 @@ def test_config2_prefix_vs_oracle_and_tiling(api, oracle, scene2):
     assert st["hits"] > n // 4 and st["bit_exact"] == 1.0
     tiled = ds.trace(rays, opts=api.make_opts(image=(4096, 256)), full=False)
     assert tiled.tobytes() == rec.tobytes()
+
+
+def test_stack_spill_path(api, oracle):
+    """Large overlapping triangles: every child box is hit at every level, so the per-lane stack
+    outgrows its LDS entries and spills to the global buffer. Results must not change."""
+    n = 6000
+    u = synth.u01(31, 0, n * 9).reshape(n, 3, 3)
+    tris = (u * np.float32(1.0)).reshape(-1, 3).astype(np.float32)          # each triangle spans the unit cube
+    blob = oracle.build_scene([dict(positions=tris)])
+    for ds in (api.DeviceScene.upload(blob), api.DeviceScene.build([dict(positions=tris)])):
+        assert ds.info()["stack_entries"] > 16
+        rays = synth.rays_config1(4096)
+        rec, ctr = ds.trace_counted(rays)
+        assert ctr["stack_spills"] > 0
+        assert ds.trace(rays, full=False).tobytes() == rec.tobytes()
+        # packet kernel on the same rays (as a 64x64 image) and its own spill path
+        popts = api.make_opts(image=(64, 64))
+        prec, pctr = ds.trace_counted(rays, popts)
+        assert prec.tobytes() == rec.tobytes()
+    # the upload keeps the oracle's BVH: bit-exact against the oracle itself
+    ds = api.DeviceScene.upload(blob)
+    hits, mask, rec = ds.trace(rays)
+    oh, om = oracle.trace(blob, rays)
+    assert (mask == om).all() and (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+    assert (hits["t"][mask] == oh["t"][om]).all()
+
+
+def test_upload_of_maximum_size_leaves(api, oracle):
+    """Blobs whose leaves hold 60-63 triangles (6-bit count, rtk.c:188) upload and trace correctly."""
+    tris = synth.triangle_soup(63, 0.3, seed=41)
+    blob = oracle.leaf_chain_blobs(tris.reshape(-1, 3, 3), chunk=63)[0]
+    ds = api.DeviceScene.upload(blob)
+    assert ds.info()["num_triangles"] == 63 and ds.info()["num_nodes"] == 1
+    rays = synth.rays_config1(4096)
+    hits, mask, _ = ds.trace(rays)
+    oh, om = oracle.trace(blob, rays)
+    assert (mask == om).all() and om.sum() > 100
+    assert (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+    assert (hits["t"][mask] == oh["t"][om]).all() and (hits["u"][mask] == oh["u"][om]).all()
