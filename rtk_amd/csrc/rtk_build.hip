@@ -957,7 +957,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
 	if (!d_nodes) return fail("out of device memory");
 	if (hipMemcpy(d_nodes, d_nodes_tmp.p, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice) != hipSuccess) return fail("copy");
-	if (hipMalloc(&ds->d_counter, 16 * sizeof(unsigned long long)) != hipSuccess) return fail("out of device memory");
+	if (hipMalloc(&ds->d_counter, RTK_COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess) return fail("out of device memory");
 	if (hipDeviceSynchronize() != hipSuccess) return fail("sync");
 
 	ds->view.nodes = d_nodes;

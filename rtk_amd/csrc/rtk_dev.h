@@ -19,6 +19,11 @@
 #define RTK_REF_NONE 0xffffffffu  // empty child slot / "no node"
 #define RTK_REF_LEAF 0x80000000u  // leaf: low 31 bits = first triangle slot
 #define RTK_TRI_LAST 1u           // DevTri.flags: last triangle of its leaf
+// Per-launch scratch words: [0] ray pool head, [1..9] visit counters, then RTK_QUEUES work-queue
+// heads, each on its own 128-byte line (one word serves only ~88 atomics/us on MI355X).
+#define RTK_QUEUES 8
+#define RTK_QUEUE_WORD(q) (16 + 16 * (q))
+#define RTK_COUNTER_WORDS (16 + 16 * RTK_QUEUES)
 
 struct DevNode {
 	float bx[2][4];

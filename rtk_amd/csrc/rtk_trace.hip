@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 	// wave-uniform ray range owned by this wave
 	unsigned long long w_next, w_end;
 	bool pool_empty;
+	uint32_t queue = blockIdx.x % RTK_QUEUES, queues_left = RTK_QUEUES;
 	if (p.dynamic) {
 		w_next = w_end = 0;
 		pool_empty = false;
@@ -114,16 +115,26 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 		const uint32_t n_idle = (uint32_t)__popcll(idle);
 		if (n_idle == 64u || (n_idle >= p.refill_min && !(pool_empty && w_next >= w_end))) {
 			if (w_next >= w_end && !pool_empty) {
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd(p.counter, (unsigned long long)RAY_CHUNK);
-				// all 64 lanes are converged here; lane 0's value becomes wave-uniform (SGPRs)
-				base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
-					(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-				if (base >= p.n) {
-					pool_empty = true;
-				} else {
-					w_next = base;
-					w_end = base + RAY_CHUNK < p.n ? base + RAY_CHUNK : p.n;
+				// chunks of 64 rays are dealt through RTK_QUEUES queue heads (chunk c belongs to queue c % 8,
+				// a wave starts on blockIdx % 8 and moves on when a queue is drained): one word only
+				// serves ~88 atomics/us, and bigger chunks per atomic unbalance the tail
+				const unsigned long long num_chunks = (p.n + 63ull) >> 6;
+				pool_empty = true;
+				while (queues_left) {
+					unsigned long long got = 0;
+					if (lane == 0) got = atomicAdd(p.counter + RTK_QUEUE_WORD(queue), 1ull);
+					// all 64 lanes are converged here; lane 0's value becomes wave-uniform (SGPRs)
+					got = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32)) << 32) |
+						(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+					const unsigned long long chunk = got * RTK_QUEUES + queue;
+					if (chunk < num_chunks) {
+						w_next = chunk << 6;
+						w_end = w_next + 64ull < p.n ? w_next + 64ull : p.n;
+						pool_empty = false;
+						break;
+					}
+					queue = (queue + 1u) % RTK_QUEUES;
+					queues_left--;
 				}
 			}
 			const unsigned long long avail = w_end - w_next;
@@ -492,7 +503,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.spill_cap = (uint32_t)spill_cap;
 	p.counter = ds->d_counter;
 
-	RTK_HIP_CHECK(hipMemsetAsync(ds->d_counter, 0, 16 * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	RTK_HIP_CHECK(hipMemsetAsync(ds->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
 	const dim3 grid((unsigned)blocks), block(BLOCK_THREADS);
 	if (packet) {
 		rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);

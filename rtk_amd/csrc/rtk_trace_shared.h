@@ -9,7 +9,6 @@
 #define TRACE_BLOCK_THREADS (64 * TRACE_WAVES_PER_BLOCK)
 #define WAVES_PER_BLOCK TRACE_WAVES_PER_BLOCK
 #define BLOCK_THREADS TRACE_BLOCK_THREADS
-#define RAY_CHUNK 64           // rays taken from the global pool per atomic
 
 struct TraceParams {
 	DevSceneView sc;

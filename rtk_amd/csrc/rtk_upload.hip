@@ -217,7 +217,7 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h)
 	bool ok = upload_vec(ds, h.nodes, &ds->view.nodes) && upload_vec(ds, h.tris, &ds->view.tris) &&
 		upload_vec(ds, h.vertex_index, &ds->view.vertex_index) && upload_vec(ds, prim_slot, &ds->view.prim_slot) &&
 		upload_vec(ds, h.slot_mesh, &ds->view.slot_mesh) && upload_vec(ds, h.slot_tri, &ds->view.slot_tri);
-	if (ok) ok = hipMalloc(&ds->d_counter, 16 * sizeof(unsigned long long)) == hipSuccess;
+	if (ok) ok = hipMalloc(&ds->d_counter, RTK_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess;
 	if (!ok) {
 		rtk_set_error("device allocation/copy failed: %s", hipGetErrorString(hipGetLastError()));
 		rtk_dev_scene_free(ds);
