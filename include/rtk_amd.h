@@ -111,7 +111,9 @@ long long rtk_dev_scene_primitive_order(const rtk_dev_scene *ds, uint32_t *out, 
 size_t rtk_dev_scene_export_size(const rtk_dev_scene *ds);
 rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *ds, void *buffer, size_t size);
 
-/* -- batches; asynchronous on `stream` -- */
+/* -- batches; asynchronous on `stream` --
+ * Launches on ONE rtk_dev_scene share its per-scene scratch (work-queue heads, stack spill area):
+ * issue them in stream order (same stream, or ordered by events). Different scenes are independent. */
 int rtk_dev_trace_rays(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, void *stream);
 int rtk_dev_trace_rays_any(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,

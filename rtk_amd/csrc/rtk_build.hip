@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <unordered_map>
 
 void rtk_cache_adopt(const rtk_scene *scene, rtk_dev_scene *ds);
@@ -1131,10 +1132,12 @@ void write_blob(const ExportPlan &ep, char *blob)
 }
 
 // one export plan is cached per scene between export_size and export
+std::mutex g_plans_mutex;
 std::unordered_map<const rtk_dev_scene *, ExportPlan *> g_plans;
 
 ExportPlan *get_plan(const rtk_dev_scene *ds)
 {
+	std::lock_guard<std::mutex> lock(g_plans_mutex);
 	auto it = g_plans.find(ds);
 	if (it != g_plans.end()) return it->second;
 	ExportPlan *ep = new ExportPlan();
@@ -1145,6 +1148,7 @@ ExportPlan *get_plan(const rtk_dev_scene *ds)
 
 void drop_plan(const rtk_dev_scene *ds)
 {
+	std::lock_guard<std::mutex> lock(g_plans_mutex);
 	auto it = g_plans.find(ds);
 	if (it != g_plans.end()) { delete it->second; g_plans.erase(it); }
 }

@@ -141,6 +141,8 @@ __device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, const i32x8 &
 	}
 	const bool neg = sse_min(sse_min(u, v), w) < 0.0f;                           // rtk.c:340-342
 	const bool pos = sse_max(sse_max(u, v), w) > 0.0f;
+	// nobody in the packet passes the sign test: skip the divide and the rest (rtk.c:344 does the same per group)
+	if (__ballot(lanes && !(neg && pos)) == 0ull) return zero;
 	const float det = (u + v) + w;                                               // rtk.c:346-353
 	const float rcp = 1.0f / det;
 	float zz = u * z0;
