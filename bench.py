@@ -297,9 +297,10 @@ def main():
             gm = g["prim"] != 0xFFFFFFFF
             both = gm & om
             mism = int((g["prim"][both] != oh["triangle_index"][both]).sum()) + int((gm != om).sum())
-            rel = float(np.max(np.abs(g["t"][both] - oh["t"][both]) / np.abs(oh["t"][both]))) if both.any() else 0.0
-            exact = float(np.mean((g["t"][both] == oh["t"][both]) & (g["u"][both] == oh["u"][both]) &
-                                  (g["v"][both] == oh["v"][both]))) if both.any() else 1.0
+            same = both & (g["prim"] == oh["triangle_index"])   # t/u/v are compared where both picked the same triangle
+            rel = float(np.max(np.abs(g["t"][same] - oh["t"][same]) / np.abs(oh["t"][same]))) if same.any() else 0.0
+            exact = float(np.mean((g["t"][same] == oh["t"][same]) & (g["u"][same] == oh["u"][same]) &
+                                  (g["v"][same] == oh["v"][same]))) if same.any() else 1.0
             return {"rays": sample, "ids_exact": mism == 0, "id_mismatches": mism, "max_rel_t": rel, "tuv_bit_exact_fraction": exact}
 
         base = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",

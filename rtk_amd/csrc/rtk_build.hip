@@ -842,7 +842,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 
 	BuildParams bp;
 	bp.cost_tri = env_float("RTK_AMD_SAH_CT", 1.0f);
-	bp.cost_node = env_float("RTK_AMD_SAH_CN", 0.5f);   // sweeps on MI355X: small leaves win (gpurun_out/sweep_sah2.log)
+	bp.cost_node = env_float("RTK_AMD_SAH_CN", 0.5f);   // sweeps on MI355X: small leaves win (profiles/r01_sweep_sah2.log)
 	bp.max_leaf = (uint32_t)env_float("RTK_AMD_MAX_LEAF", 8.0f);
 	if (bp.max_leaf < 1) bp.max_leaf = 1;
 	if (bp.max_leaf > 63) bp.max_leaf = 63;     // 6-bit count in the blob's leaf header (rtk.c:188)

@@ -448,7 +448,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.occluded = d_occluded;
 	p.n = n;
 	p.dynamic = 1;
-	// Defaults from sweeps on MI355X (gpurun_out/sweep_opts*.log): leave the node
+	// Defaults from sweeps on MI355X (profiles/r01_sweep_opts*.log): leave the node
 	// loop once fewer than 24 lanes still descend; image-shaped (tiled, coherent) batches refill a
 	// wave only when it is empty, everything else as soon as 8 lanes are idle.
 	p.refill_min = 8;

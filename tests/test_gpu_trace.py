@@ -221,3 +221,32 @@ def test_upload_of_maximum_size_leaves(api, oracle):
     assert (mask == om).all() and om.sum() > 100
     assert (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
     assert (hits["t"][mask] == oh["t"][om]).all() and (hits["u"][mask] == oh["u"][om]).all()
+
+
+def test_special_rays_take_the_exact_min_max_path(api, oracle, scene1):
+    """Rays with zero / negative-zero / tiny / huge direction components (0*inf = NaN in the slab test)
+    force the SSE-ordered min/max path (rtk.c:464-465) in both kernels; mixed signs and dominant axes
+    inside one wave force the per-lane variants of the packet kernel. Bit-exact against the oracle."""
+    blob, ds = scene1
+    rays = synth.rays_config1(4096).copy()
+    n = len(rays)
+    k = np.arange(n)
+    d = rays["direction"]
+    d[k % 7 == 0, 0] = 0.0
+    d[k % 11 == 0, 1] = -0.0
+    d[k % 13 == 0, 0] = 1e-42          # denormal: 1/d overflows to inf
+    d[k % 17 == 0, 2] = 1e30
+    d[k % 19 == 0] *= -1.0             # mixed signs in a wave
+    d[k % 23 == 0] = d[k % 23 == 0][:, [2, 0, 1]]   # other dominant axes
+    rays["origin"][k % 29 == 0, 0] = 0.5
+    # origins exactly on vertex coordinates of the scene: bound - origin == 0 happens for real
+    tris = synth.scene_for_config(1)
+    rays["origin"][k % 31 == 0, 0] = tris[(k[k % 31 == 0] * 3) % len(tris), 0]
+    rays["direction"] = d
+    oh, om = oracle.trace(blob, rays)
+    for opts in (None, api.make_opts(image=(64, 64)), api.make_opts(static=True)):
+        hits, mask, _ = ds.trace(rays, opts=opts)
+        assert (mask == om).all()
+        assert (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+        assert (hits["t"][mask] == oh["t"][om]).all() and (hits["u"][mask] == oh["u"][om]).all() and (hits["v"][mask] == oh["v"][om]).all()
+    assert om.sum() > 500
