@@ -193,10 +193,26 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
+    elapsed_no_gather = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if gather:
+            # the same K steps with the records left on their GPU: at ~7 Grays/s one GPU produces
+            # ~110 GB/s of hit records, more than one xGMI link direction carries, so the gather can
+            # be what bounds `value`; this second figure shows the traversal scaling by itself
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                trace(d_outs[k % len(d_outs)])
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            elapsed_no_gather = float(t2.item())
     d_out = d_outs[(args.steps - 1) % len(d_outs)] if args.steps else d_outs[0]
 
     # ---- the result that was timed ---------------------------------------------------------
@@ -248,7 +264,8 @@ def main():
                    "bvh_build_ms_device_resident_mesh": round(build_ms_device_mesh, 2) if build_ms_device_mesh else None,
                    "bvh_build_mtris_s_device_resident_mesh": round(cfg["num_tris"] / build_ms_device_mesh / 1e3, 1) if build_ms_device_mesh else None,
                    "hit_fraction": round(hit_frac, 4),
-                   "gather": ("records to rank 0 over RCCL, overlapped with the next step's trace" if gather else None), "launch": "static" if args.static else "persistent",
+                   "gather": ("records to rank 0 over RCCL, overlapped with the next step's trace" if gather else None), "value_without_gather_mrays_s": round(n * world * args.steps / elapsed_no_gather / 1e6, 2) if elapsed_no_gather else None,
+                   "launch": "static" if args.static else "persistent",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
