@@ -58,7 +58,11 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--node-exit", type=int, default=0)
     ap.add_argument("--frame", type=int, default=4096)
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU: gloo + CPU tensors + a stand-in tracer that only fills buffers; exercises the "
+                         "multi-rank step loop / gather / timing / JSON plumbing in the CPU tests. Prints no perf claim.")
     args = ap.parse_args()
+    DRY = args.dry_run_cpu
 
     import torch
     import torch.distributed as dist
@@ -71,11 +75,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
-    local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    api.lib().rtk_amd_set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = "cpu" if DRY else "cuda"
+
+    def sync():
+        if not DRY:
+            torch.cuda.synchronize()
+
+    if DRY:
+        args.no_cpu_baseline = True
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        local_rank %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        api.lib().rtk_amd_set_device(local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     W = H = args.frame
     n = W * H
@@ -83,12 +98,30 @@ def main():
     cfg = synth.CONFIGS[5 if shadow else 2]
 
     # ---- scene: replicated on every rank -------------------------------------------------
+    class _StandIn:
+        """--dry-run-cpu only: fills the output with a pattern; nothing is traced."""
+        def info(self):
+            return dict(num_nodes=0, build_ms=0.0)
+
+        def trace_device(self, d_rays, n, buf, opts):
+            buf.fill_((rank * 13 + 1) % 251)
+
+        trace_any_device = trace_device
+
+        def trace_counted(self, rays, opts):
+            return None, dict(nodes=0, leaves=0, triangles=0, wave_node_steps=0, wave_triangle_steps=0)
+
+        trace_any_counted = trace_counted
+
     t0 = time.time()
-    tris = synth.triangle_soup(cfg["num_tris"], cfg["spread"], cfg["scene_seed"])
+    tris = None if DRY else synth.triangle_soup(cfg["num_tris"], cfg["spread"], cfg["scene_seed"])
     t_gen = time.time() - t0
     t0 = time.time()
     oracle_blob = None
-    if args.bvh == "device":
+    if DRY:
+        ds = _StandIn()
+        bvh_kind = "none (dry run)"
+    elif args.bvh == "device":
         ds = api.DeviceScene.build([dict(positions=tris)])
         bvh_kind = "gpu-lbvh"
     else:
@@ -96,12 +129,12 @@ def main():
         oracle_blob = pyoracle.build_scene([dict(positions=tris)])
         ds = api.DeviceScene.upload(oracle_blob)
         bvh_kind = "oracle-sah-blob-upload"
-    torch.cuda.synchronize()
+    sync()
     t_build = time.time() - t0
     info = ds.info()
     build_ms_first_call = info["build_ms"]
     build_ms_device_mesh = None
-    if shadow and args.bvh == "device":
+    if shadow and args.bvh == "device" and not DRY:
         # the first build of a process also pays one-time costs (code-object load, first touch of the
         # host pages by the DMA engine); build again for the steady-state figure, and once more with the
         # mesh already resident in HBM (no PCIe upload inside the build)
@@ -109,7 +142,7 @@ def main():
         ds = api.DeviceScene.build([dict(positions=tris)])
         info = ds.info()
         d_tris = torch.from_numpy(tris).cuda()
-        torch.cuda.synchronize()
+        sync()
         ds2 = api.DeviceScene.build([dict(positions=d_tris)])
         build_ms_device_mesh = ds2.info()["build_ms"]
         ds2.free()
@@ -135,13 +168,13 @@ def main():
         opts = api.make_opts(**common)
         workload = "config5: 10M-tri soup (spread 0.01), GPU LBVH build + %d any-hit shadow rays" % n
         metric = "Mrays/sec (any-hit shadow) on 10M-tri scene"
-    d_rays = api.to_device(rays)
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)) if DRY else api.to_device(rays)
     out_bytes = 1 if shadow else HIT_BYTES
     # two output buffers: with N > 1 the gather of step k overlaps the trace of step k+1
-    d_outs = [torch.empty(n * out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+    d_outs = [torch.empty(n * out_bytes, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
     sizes = [n * out_bytes] * world
     gather = world > 1 and not args.no_gather
-    gathered = [torch.empty(sum(sizes), dtype=torch.uint8, device="cuda") if (gather and rank == 0) else None for _ in d_outs]
+    gathered = [torch.empty(sum(sizes), dtype=torch.uint8, device=dev) if (gather and rank == 0) else None for _ in d_outs]
     pending = [[] for _ in d_outs]
 
     def trace(buf):
@@ -170,32 +203,40 @@ def main():
     # ---- algorithmic bytes from the counting build (not timed) ----------------------------
     _, ctr = ds.trace_any_counted(rays, opts) if shadow else ds.trace_counted(rays, opts)
     alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
-    torch.cuda.synchronize()
+    sync()
 
     for k in range(args.warmup):
         step(k)
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     # ---- timed region --------------------------------------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    class _WallEvent:
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    mk_event = _WallEvent if DRY else (lambda: torch.cuda.Event(enable_timing=True))
+    ev = [(mk_event(), mk_event()) for _ in range(args.steps)]
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(k, ev[k])
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     elapsed_no_gather = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         if gather:
@@ -203,14 +244,14 @@ def main():
             # ~110 GB/s of hit records, more than one xGMI link direction carries, so the gather can
             # be what bounds `value`; this second figure shows the traversal scaling by itself
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
             t1 = time.perf_counter()
             for k in range(args.steps):
                 trace(d_outs[k % len(d_outs)])
-            torch.cuda.synchronize()
+            sync()
             dist.barrier()
-            torch.cuda.synchronize()
-            t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            sync()
+            t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             elapsed_no_gather = float(t2.item())
     d_out = d_outs[(args.steps - 1) % len(d_outs)] if args.steps else d_outs[0]
@@ -256,7 +297,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not DRY else "none: --dry-run-cpu plumbing check, not a measurement",
         "config": {"workload": workload, "rays_per_gpu_per_step": n, "bvh": bvh_kind, "bvh_nodes": info["num_nodes"],
                    "bvh_build_s": round(t_build, 3), "bvh_build_ms_first_call": round(build_ms_first_call, 2),
                    "bvh_build_ms_in_library": round(info["build_ms"], 2),

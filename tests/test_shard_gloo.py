@@ -93,3 +93,22 @@ def test_pipelined_gather_two_ranks(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_pipelined_worker, args=(2, _free_port(), 257, 6, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_multi_rank_plumbing_dry_run():
+    """bench.py's N=2 control flow (env ranks, gloo, double-buffered gather, barrier/max timing, one
+    JSON line from rank 0) with the tracer replaced by a stand-in: catches plumbing errors that the
+    one-GPU box cannot (the driver runs N>1 only at round end)."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu", "--frame", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["gather"] and d["config"]["value_without_gather_mrays_s"] > 0
+    assert "dry-run" in d["data"]
