@@ -24,3 +24,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def api():
+    """The product binding (rtk_amd.api over librtk_amd.so). Builds the library first if a fresh
+    checkout does not have it yet; never substitutes anything for it."""
+    from rtk_amd import api as _api
+    if not os.path.exists(_api.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    _api.lib()
+    return _api

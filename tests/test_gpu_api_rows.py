@@ -17,13 +17,6 @@ LOG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_char_p)
 FILTER_CB = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
-@pytest.fixture(scope="module")
-def api():
-    from rtk_amd import api
-    api.lib()
-    return api
-
-
 def _trace(api, ds, rays):
     return ds.trace(rays, full=True)
 

@@ -13,13 +13,6 @@ from tests.util import compare_hits, compare_hits_struct, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def api():
-    from rtk_amd import api
-    api.lib()
-    return api
-
-
 def _as_blob(oracle, arr):
     b = oracle._aligned_bytes(arr.size)
     b[:] = arr

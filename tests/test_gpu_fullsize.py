@@ -13,13 +13,6 @@ N = 1 << 24
 
 
 @pytest.fixture(scope="module")
-def api():
-    from rtk_amd import api
-    api.lib()
-    return api
-
-
-@pytest.fixture(scope="module")
 def scene(api):
     tris = synth.scene_for_config(2)
     return tris, api.DeviceScene.build([dict(positions=tris)])

@@ -13,13 +13,6 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def api():
-    from rtk_amd import api
-    api.lib()
-    return api
-
-
-@pytest.fixture(scope="module")
 def scene1(oracle, api):
     tris = synth.scene_for_config(1)
     blob = oracle.build_scene([dict(positions=tris)])
