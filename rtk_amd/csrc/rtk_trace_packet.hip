@@ -343,6 +343,24 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					// one child for the whole packet: a lane enters it iff it enters anything
 					live = e0 || e1 || e2 || e3;
 					top = a0 ? ref[0] : (a1 ? ref[1] : (a2 ? ref[2] : ref[3]));
+				} else if (n_any == 2u) {
+					// two children: pick them out (wave-uniform slot numbers), one comparison, one push
+					const uint32_t m = (a0 ? 1u : 0u) | (a1 ? 2u : 0u) | (a2 ? 4u : 0u) | (a3 ? 8u : 0u);
+					const uint32_t i0 = (uint32_t)__builtin_ctz(m), i1 = (uint32_t)__builtin_ctz(m & (m - 1u));
+					const float p0 = i0 == 0u ? pay[0] : (i0 == 1u ? pay[1] : pay[2]);            // i0 is 0, 1 or 2
+					const float p1 = i1 == 1u ? pay[1] : (i1 == 2u ? pay[2] : pay[3]);            // i1 is 1, 2 or 3
+					const uint32_t r0 = i0 == 0u ? ref[0] : (i0 == 1u ? ref[1] : ref[2]);
+					const uint32_t r1 = i1 == 1u ? ref[1] : (i1 == 2u ? ref[2] : ref[3]);
+					const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
+					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
+					const bool swap = k1 < k0;
+					const float pfar = swap ? p0 : p1, pnear = swap ? p1 : p0;
+					if (sp < PK_LDS_STACK) lds_t[sp][lane] = pfar;
+					else if (sp - PK_LDS_STACK < p.spill_cap) { spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane] = pfar; if (COUNT) c_spills++; }
+					stack = stack_write(stack, swap ? r0 : r1, sp, lane);
+					sp++;
+					live = pnear == pnear;
+					top = swap ? r1 : r0;
 				} else {
 					// order by the entry distance seen by the first live lane; its own misses (NaN) sort behind
 					// its hits, children nobody enters sort last. Keys per lane on the VALU, one readlane each.
