@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--static", action="store_true", help="A/B: one fixed ray per lane instead of persistent refill")
     ap.add_argument("--no-tiling", action="store_true")
     ap.add_argument("--no-packet", action="store_true", help="A/B: image-shaped batch on the per-lane kernel")
+    ap.add_argument("--sort-rays", action="store_true", help="reorder the batch by origin cell + direction octant first (inside the timed step)")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--node-exit", type=int, default=0)
@@ -152,7 +153,7 @@ def main():
 
     # ---- rays: frame `rank` of config 4 (frame 0 == config 2) ------------------------------
     common = dict(static=args.static, refill_min=args.refill_min, blocks_per_cu=args.blocks_per_cu, node_exit=args.node_exit,
-                  no_packet=args.no_packet)
+                  no_packet=args.no_packet, sort_rays=args.sort_rays)
     if args.workload == "coherent":
         rays = synth.rays_pinhole(W, H, jitter=synth.frame_jitter(rank))
         opts = api.make_opts(image=None if args.no_tiling else (W, H), **common)

@@ -84,6 +84,8 @@ typedef struct rtk_trace_opts {
 } rtk_trace_opts;
 #define RTK_TRACE_STATIC    1u   /* one fixed ray per lane, no persistent refill (A/B only) */
 #define RTK_TRACE_NO_PACKET 2u   /* image-shaped batch, but use the per-lane kernel (A/B only) */
+#define RTK_TRACE_SORT_RAYS 4u   /* reorder the batch by (origin cell, direction octant) before tracing; hits
+                                    still land in input order. Pays off for large incoherent batches. */
 
 /* Visit counters of the counting build (algorithmic-bytes model). */
 typedef struct rtk_trace_counters {

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(HERE, "librtk_amd.so")
 
 RTK_TRACE_STATIC = 1
 RTK_TRACE_NO_PACKET = 2
+RTK_TRACE_SORT_RAYS = 4
 
 
 class RtkError(RuntimeError):
@@ -145,10 +146,10 @@ def to_device(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False):
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
-    o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0)
+    o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

@@ -735,6 +735,40 @@ rtk_dev_scene *build_tiny(const rtk_scene_desc *desc, const std::vector<uint64_t
 
 } // namespace
 
+// Asynchronous radix sort of (64-bit key, 32-bit value) pairs on `stream`, low `key_bits` bits only
+// (rounded up to whole 8-bit passes). Ping-pongs between the a/b buffers; returns true if the result
+// is in the b buffers. scratch: rtk_sort_scratch_words(n) uint32 words. No allocation, no sync.
+size_t rtk_sort_scratch_words(uint32_t n)
+{
+	const size_t num_units = ((size_t)n + SORT_TILE - 1u) / SORT_TILE;
+	const size_t hist = 256 * num_units;
+	const size_t sums = (hist + (size_t)SCAN_BLOCK * SCAN_ITEMS - 1) / ((size_t)SCAN_BLOCK * SCAN_ITEMS);
+	return hist + sums + 16;
+}
+
+bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+	uint32_t n, uint32_t key_bits, uint32_t *scratch, hipStream_t stream)
+{
+	const uint32_t num_units = (n + SORT_TILE - 1u) / SORT_TILE;
+	const size_t hist_n = 256 * (size_t)num_units;
+	uint32_t *hist = scratch, *sums = scratch + hist_n;
+	const size_t scan_blocks = (hist_n + (size_t)SCAN_BLOCK * SCAN_ITEMS - 1) / ((size_t)SCAN_BLOCK * SCAN_ITEMS);
+	unsigned long long *kin = keys_a, *kout = keys_b;
+	uint32_t *vin = vals_a, *vout = vals_b;
+	bool in_b = false;
+	for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+		hipLaunchKernelGGL(k_sort_hist, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, n, shift, num_units, hist);
+		hipLaunchKernelGGL(k_scan_block, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
+		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)scan_blocks);
+		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
+		hipLaunchKernelGGL(k_sort_scatter, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout);
+		std::swap(kin, kout);
+		std::swap(vin, vout);
+		in_b = !in_b;
+	}
+	return in_b;
+}
+
 // =====================================================================================
 // rtk_dev_scene_build
 // =====================================================================================

@@ -58,6 +58,7 @@ extern "C" void rtk_dev_scene_free(rtk_dev_scene *ds)
 	for (void *p : ds->allocs) (void)hipFree(p);
 	if (ds->d_counter) (void)hipFree(ds->d_counter);
 	if (ds->d_spill) (void)hipFree(ds->d_spill);
+	if (ds->d_sort) (void)hipFree(ds->d_sort);
 	delete ds;
 }
 

@@ -68,6 +68,9 @@ struct rtk_dev_scene {
 	// per-scene scratch for launches (lazily sized)
 	unsigned long long *d_counter = nullptr;   // ray pool head + visit counters (8 x u64)
 	uint2 *d_spill = nullptr;
+	// ray reordering scratch (RTK_TRACE_SORT_RAYS), grown on demand
+	void *d_sort = nullptr;
+	size_t sort_capacity = 0;                   // rays
 	size_t spill_entries_per_lane = 0;
 	size_t spill_lanes = 0;
 	int num_cus = 0;
@@ -95,6 +98,11 @@ struct HostBvh {
 };
 int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out);
 rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
+
+// -- radix sort shared with the builder (rtk_build.hip) --
+size_t rtk_sort_scratch_words(uint32_t n);
+bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+	uint32_t n, uint32_t key_bits, uint32_t *scratch, hipStream_t stream);
 
 // -- trace launches (rtk_trace.hip) --
 int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,

@@ -18,6 +18,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 __device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					__builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
 				if (!active && rank < take) {
-					ray_index = map_index(w_next + rank, p.image_w, p.image_h);
+					ray_index = p.perm ? (unsigned long long)p.perm[w_next + rank] : map_index(w_next + rank, p.image_w, p.image_h);
 					const float4 r0 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index));
 					const float4 r1 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
 					ox = r0.x; oy = r0.y; oz = r0.z;
@@ -393,6 +394,63 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 	}
 }
 
+// ---- ray reordering (RTK_TRACE_SORT_RAYS): 16-bit key = 4 bits of origin cell per axis inside the
+// batch's origin bounds + direction octant; rays of one key start close together and head the same way,
+// so the 64 rays a wave pulls from the sorted order share nodes (L1/L2 hits instead of fabric traffic).
+__device__ __forceinline__ uint32_t f2ord_(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ord2f_(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ void rtk_ray_bounds_kernel(const rtk_ray *rays, unsigned long long n, uint32_t *bounds)
+{
+	__shared__ float s_mn[3][4], s_mx[3][4];
+	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+		const float4 r0 = *reinterpret_cast<const float4 *>(rays + i);
+		const float o[3] = { r0.x, r0.y, r0.z };
+		for (int a = 0; a < 3; a++) if (isfinite(o[a])) { mn[a] = fminf(mn[a], o[a]); mx[a] = fmaxf(mx[a], o[a]); }
+	}
+	for (int a = 0; a < 3; a++) {
+		for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
+		if ((threadIdx.x & 63u) == 0) { s_mn[a][threadIdx.x >> 6] = mn[a]; s_mx[a][threadIdx.x >> 6] = mx[a]; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		const int a = threadIdx.x;
+		float lo = s_mn[a][0], hi = s_mx[a][0];
+		for (int w = 1; w < 4; w++) { lo = fminf(lo, s_mn[a][w]); hi = fmaxf(hi, s_mx[a][w]); }
+		atomicMin(&bounds[a], f2ord_(lo));
+		atomicMax(&bounds[3 + a], f2ord_(hi));
+	}
+}
+
+__global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals,
+	uint32_t cell_bits, uint32_t with_octant)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4 r0 = *reinterpret_cast<const float4 *>(rays + i);
+	const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rays + i) + 16);
+	const float o[3] = { r0.x, r0.y, r0.z };
+	const uint32_t cells = 1u << cell_bits;
+	uint32_t q[3];
+	for (int a = 0; a < 3; a++) {
+		const float lo = ord2f_(bounds[a]), hi = ord2f_(bounds[3 + a]);
+		const float ext = hi - lo;
+		float t = ext > 0.0f ? (o[a] - lo) / ext : 0.0f;
+		t = t >= 0.0f ? (t <= 1.0f ? t : 1.0f) : 0.0f;           // NaN -> 0
+		const uint32_t c = (uint32_t)(t * (float)cells);
+		q[a] = c > cells - 1u ? cells - 1u : c;
+	}
+	// Morton-interleave the cell coordinates (x lowest) so that consecutive keys are neighbours in space
+	uint32_t key = 0;
+	for (uint32_t b = 0; b < cell_bits; b++)
+		key |= (((q[0] >> b) & 1u) << (3u * b)) | (((q[1] >> b) & 1u) << (3u * b + 1u)) | (((q[2] >> b) & 1u) << (3u * b + 2u));
+	if (with_octant)
+		key = (key << 3) | ((__float_as_uint(r0.w) >> 31) | ((__float_as_uint(r1.x) >> 31) << 1) | ((__float_as_uint(r1.y) >> 31) << 2));
+	keys[i] = key;
+	vals[i] = i;
+}
+
 // Full rtk_hit from a compact record (rtk.c:372-380 copy-out).
 __global__ void rtk_expand_kernel(DevSceneView sc, const rtk_hit_record *rec, unsigned long long n, rtk_hit *hits, uint8_t *mask)
 {
@@ -497,6 +555,32 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		RTK_HIP_CHECK(hipMalloc(&ds->d_spill, lanes * spill_cap * sizeof(uint2)), RTK_AMD_ERR_OOM);
 		ds->spill_lanes = lanes;
 		ds->spill_entries_per_lane = spill_cap;
+	}
+	// optional ray reordering pre-pass (per-lane kernels only)
+	p.perm = nullptr;
+	if (!packet && opts && (opts->flags & RTK_TRACE_SORT_RAYS) && n < 0x7fffffffu) {
+		const uint32_t n32 = (uint32_t)n;
+		const size_t words = rtk_sort_scratch_words(n32);
+		if (ds->sort_capacity < n) {
+			if (ds->d_sort) (void)hipFree(ds->d_sort);
+			ds->d_sort = nullptr;
+			ds->sort_capacity = 0;
+			// [keys_a | keys_b] 8 B each, [vals_a | vals_b] 4 B each, bounds 6 words + sort scratch
+			RTK_HIP_CHECK(hipMalloc(&ds->d_sort, n * 24 + (words + 16) * 4), RTK_AMD_ERR_OOM);
+			ds->sort_capacity = n;
+		}
+		unsigned long long *keys_a = (unsigned long long *)ds->d_sort, *keys_b = keys_a + ds->sort_capacity;
+		uint32_t *vals_a = (uint32_t *)(keys_b + ds->sort_capacity), *vals_b = vals_a + ds->sort_capacity;
+		uint32_t *bounds = vals_b + ds->sort_capacity, *scratch = bounds + 16;
+		static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+		RTK_HIP_CHECK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream), RTK_AMD_ERR_HIP);
+		hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(256), 0, stream, d_rays, (unsigned long long)n, bounds);
+		static const uint32_t cell_bits = getenv("RTK_AMD_SORT_CELL_BITS") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_CELL_BITS")) : 5u;
+		static const uint32_t with_octant = getenv("RTK_AMD_SORT_OCTANT") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_OCTANT")) : 0u;
+		hipLaunchKernelGGL(rtk_ray_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, bounds, keys_a, vals_a,
+			cell_bits, with_octant);
+		const bool in_b = rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n32, 3u * cell_bits + (with_octant ? 3u : 0u), scratch, stream);
+		p.perm = in_b ? vals_b : vals_a;
 	}
 	p.spill = ds->d_spill;
 	p.spill_stride = (uint32_t)(spill_cap ? ds->spill_lanes : 0);

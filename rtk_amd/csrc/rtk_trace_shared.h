@@ -24,6 +24,7 @@ struct TraceParams {
 	uint32_t refill_min;
 	uint32_t dynamic;
 	uint32_t node_exit;            // leave the node loop when fewer lanes than this still need node steps and a leaf is waiting
+	const uint32_t *perm;          // optional: trace rays in this order (ray reordering), results go to the ray's own slot
 };
 
 // _mm_min_ps/_mm_max_ps semantics (second operand when the compare is false, NaN included)

@@ -3,8 +3,9 @@ timeout -k 10 600 python -m pytest tests/test_gpu_trace.py -m gpu -q -x > gpurun
 run() { timeout -k 10 120 python bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$*', d['value'], 'Mrays/s', d['roofline']['kernel_ms'])" || exit 1; }
+print('$*', d['value'], 'Mrays/s', d['roofline']['kernel_ms'], d['config']['hit_fraction'])" || exit 1; }
 run --workload coherent
-run --workload coherent --no-packet
 run --workload incoherent
+run --workload incoherent --sort-rays
 run --workload shadow
+run --workload shadow --sort-rays

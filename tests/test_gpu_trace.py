@@ -71,7 +71,8 @@ def test_edge_cases_vs_golden(api, oracle, golden_dir):
     compare_hits_struct(hits2, mask2, g, "gpu/edge single leaf")
 
 
-@pytest.mark.parametrize("mode", ["static", "refill8", "tiled", "tiled_per_lane", "node_exit16", "node_exit64_refill8", "node_exit64_static"])
+@pytest.mark.parametrize("mode", ["static", "refill8", "tiled", "tiled_per_lane", "node_exit16", "node_exit64_refill8", "node_exit64_static",
+                                  "sort_rays", "sort_rays_static"])
 def test_launch_modes_agree(api, scene1, mode):
     _, ds = scene1
     rays = synth.rays_config1(65536)
@@ -82,6 +83,10 @@ def test_launch_modes_agree(api, scene1, mode):
         opts = api.make_opts(refill_min=8, blocks_per_cu=1)
     elif mode == "tiled_per_lane":
         opts = api.make_opts(image=(256, 256), no_packet=True)
+    elif mode == "sort_rays":
+        opts = api.make_opts(sort_rays=True)
+    elif mode == "sort_rays_static":
+        opts = api.make_opts(sort_rays=True, static=True)
     elif mode == "node_exit16":
         opts = api.make_opts(node_exit=16)
     elif mode == "node_exit64_refill8":
