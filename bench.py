@@ -357,10 +357,13 @@ def main():
             both = gm & om
             mism = int((g["prim"][both] != oh["triangle_index"][both]).sum()) + int((gm != om).sum())
             same = both & (g["prim"] == oh["triangle_index"])   # t/u/v are compared where both picked the same triangle
-            rel = float(np.max(np.abs(g["t"][same] - oh["t"][same]) / np.abs(oh["t"][same]))) if same.any() else 0.0
+            relv = np.abs(g["t"][same] - oh["t"][same]) / np.abs(oh["t"][same]) if same.any() else np.zeros(1)
+            rel = float(relv.max())
+            t_at = float(oh["t"][same][int(relv.argmax())]) if same.any() else 0.0   # large only where t itself is ~0 (cancellation)
             exact = float(np.mean((g["t"][same] == oh["t"][same]) & (g["u"][same] == oh["u"][same]) &
                                   (g["v"][same] == oh["v"][same]))) if same.any() else 1.0
-            return {"rays": sample, "ids_exact": mism == 0, "id_mismatches": mism, "max_rel_t": rel, "tuv_bit_exact_fraction": exact}
+            return {"rays": sample, "ids_exact": mism == 0, "id_mismatches": mism, "max_rel_t": rel, "t_at_max_rel_t": t_at,
+                    "tuv_bit_exact_fraction": exact}
 
         base = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": "%d rays = every %d-th ray of the same batch, closest-hit on the oracle's SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"
