@@ -56,3 +56,44 @@ def test_missing_gpu_is_loud_not_a_fallback():
         pytest.skip("GPU present")
     with pytest.raises(api.RtkError):
         api.DeviceScene.upload(np.zeros(512, np.uint8))
+
+
+def test_blob_validator_rejects_corrupt_scenes_without_a_gpu(oracle):
+    """rtk_dev_scene_upload validates the whole blob on the host before touching HIP: every corruption
+    is refused with a message; a VALID blob then fails loudly for lack of a device (no CPU fallback)."""
+    import torch
+    from rtk_amd import synth
+    L = api.lib()
+    blob = oracle.build_scene([dict(positions=synth.triangle_soup(500, 0.1, seed=5))])
+    good = blob.data.copy()
+
+    def upload(arr):
+        a = np.ascontiguousarray(arr)
+        h = L.rtk_dev_scene_upload(C.c_void_p(a.ctypes.data))
+        return h, api.last_error()
+
+    bad = good.copy(); bad[1] = ord("X")
+    h, err = upload(bad); assert not h and "magic" in err
+    bad = good.copy(); bad[8:10] = (0xaa, 0xbb)                    # big-endian marker
+    h, err = upload(bad); assert not h and "endian" in err
+    bad = good.copy(); bad[10] = 8                                  # sizeof_real = 8
+    h, err = upload(bad); assert not h and "sizeof_real" in err
+    hdr = types.SceneHeader.from_buffer_copy(good[:56].tobytes())
+    bad = good.copy(); bad[24:32] = np.frombuffer(np.uint64(200).tobytes(), np.uint8)   # size_in_bytes too small
+    h, err = upload(bad); assert not h
+    # a child pointer far outside the blob
+    bad = good.copy(); bad[128 + 96:128 + 104] = np.frombuffer(np.uint64(hdr.size_in_bytes * 4).tobytes(), np.uint8)
+    h, err = upload(bad); assert not h and "out of range" in err
+    # a leaf whose vertex group points outside
+    nodes = good[128:hdr.leaf_offset].view(np.uint64).reshape(-1, 16)
+    leaf_ptrs = nodes[:, 12:16].reshape(-1)
+    first_leaf = int(leaf_ptrs[(leaf_ptrs & 1) == 1][0]) ^ 1
+    while good[first_leaf:first_leaf + 8].view(np.uint64)[0] & 0x3f == 0:      # skip the null leaf
+        first_leaf = int(leaf_ptrs[(leaf_ptrs & 1) == 1][np.random.RandomState(0).randint(1, 50)]) ^ 1
+    bad = good.copy()
+    info = int(bad[first_leaf:first_leaf + 8].view(np.uint64)[0])
+    bad[first_leaf:first_leaf + 8] = np.frombuffer(np.uint64((info & 0x3f) | ((hdr.size_in_bytes * 2) & ~0x3f)).tobytes(), np.uint8)
+    h, err = upload(bad); assert not h and "vertex" in err
+    if not torch.cuda.is_available():
+        h, err = upload(good)
+        assert not h and "HIP device" in err
