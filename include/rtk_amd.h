@@ -101,7 +101,12 @@ typedef struct rtk_trace_counters {
 } rtk_trace_counters;
 
 /* -- scenes -- */
+/* Validates the blob (every offset range-checked without wrap-around; it must be a tree: a node or leaf
+ * reached twice is refused) and lays it out in HBM. rtk_dev_scene_upload trusts scene->size_in_bytes to be
+ * readable, as the reference's bare rtk_scene* forces it to; a loader of untrusted files uses
+ * rtk_dev_scene_upload_buffer, which also checks the header against the buffer size. */
 rtk_dev_scene *rtk_dev_scene_upload(const rtk_scene *scene);
+rtk_dev_scene *rtk_dev_scene_upload_buffer(const void *blob, size_t blob_bytes);
 rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc);
 void rtk_dev_scene_free(rtk_dev_scene *ds);
 int rtk_dev_scene_get_info(const rtk_dev_scene *ds, rtk_dev_scene_info *info);
@@ -113,15 +118,68 @@ long long rtk_dev_scene_primitive_order(const rtk_dev_scene *ds, uint32_t *out, 
 size_t rtk_dev_scene_export_size(const rtk_dev_scene *ds);
 rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *ds, void *buffer, size_t size);
 
+/* Structural check of a device scene, run on the device (the loader/validator the reference lacks,
+ * SURVEY.md section 5; blob-level checks happen in rtk_dev_scene_upload). Every child box must contain
+ * what is below it, every triangle slot must sit in exactly one leaf, every node but the root must be
+ * referenced exactly once by an earlier node, leaf headers must be well formed (1..63 triangles,
+ * rtk.c:188). Returns RTK_AMD_OK when all error counts are zero, RTK_AMD_ERR_BAD_SCENE otherwise;
+ * `loose_boxes` (a box that contains its contents without being their exact union) is legal and only
+ * reported. content_hash covers nodes and triangle records: equal for two builds of the same input. */
+typedef struct rtk_dev_scene_check {
+	uint64_t nodes_checked, leaves_checked, triangles_checked;
+	uint64_t box_violations;        /* child box does not contain its subtree / empty slot can be hit */
+	uint64_t loose_boxes;
+	uint64_t bad_references;        /* child index out of range or not after its parent */
+	uint64_t leaf_format_errors;
+	uint64_t triangles_missing, triangles_duplicated;
+	uint64_t nodes_unreachable, nodes_shared;
+	uint64_t primitive_id_errors;   /* id out of range, repeated, or prim -> slot table inconsistent */
+	uint64_t first_bad_index;       /* smallest node / slot index that raised an error, ~0 if none */
+	uint64_t content_hash;
+} rtk_dev_scene_check;
+int rtk_dev_scene_validate(const rtk_dev_scene *ds, rtk_dev_scene_check *out);
+
+/* Device builds draw their temporaries from one workspace per device that is kept between builds
+ * (about 330 bytes per triangle); this releases it. */
+void rtk_amd_release_workspace(void);
+
 /* -- batches; asynchronous on `stream` --
- * Launches on ONE rtk_dev_scene share its per-scene scratch (work-queue heads, stack spill area):
- * issue them in stream order (same stream, or ordered by events). Different scenes are independent. */
+ * Thread-safe: a scene is never modified by a launch. What a launch writes besides its outputs (work-queue
+ * heads, the global part of the traversal stacks) lives in a scratch set per (scene, stream), so launches on
+ * different streams or from different host threads never share state; launches on one stream are ordered by
+ * the stream (reference: rtk_trace_ray is a pure function of a const scene, rtk.c:543-577). */
 int rtk_dev_trace_rays(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, void *stream);
 int rtk_dev_trace_rays_any(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, void *stream);
 int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n,
 	rtk_hit *d_hits, uint8_t *d_mask, void *stream);
+/* Built-in candidate filters evaluated on the device (reference rtk.h:117,130: rtk_filter_fn /
+ * rtk_trace_ray_filter, a stub at rtk.c:579-582; arbitrary C callbacks cannot run on the GPU, these cover
+ * the common ones). A candidate hit is considered only if EVERY filter that is set accepts it; the result is
+ * the closest accepted candidate (closest-hit call) or "is there an accepted candidate" (any-hit call).
+ *   d_mesh_mask    bit m (word m/32, bit m%32) set = triangles of mesh m are visible; meshes >= mesh_mask_bits are not
+ *   d_ignore_prim  one per ray: global primitive id that is never a candidate (self-intersection); RTK_PRIM_NONE = none
+ *   d_after        one per ray: only candidates that come AFTER (t, prim) in lexicographic (t, prim) order are
+ *                  considered; prim = RTK_PRIM_NONE switches it off for that ray. Feeding a ray's previous result
+ *                  back enumerates ALL candidates of the ray in order, equal-t ones included -- the device half of
+ *                  rtk_trace_rays_filter's host-callback loop.
+ * All pointers are device memory and optional (NULL). */
+typedef struct rtk_dev_filter {
+	uint32_t struct_size;               /* sizeof(rtk_dev_filter) */
+	uint32_t mesh_mask_bits;
+	const uint32_t *d_mesh_mask;
+	const uint32_t *d_ignore_prim;
+	const rtk_hit_record *d_after;
+} rtk_dev_filter;
+int rtk_dev_trace_rays_filtered(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	rtk_hit_record *d_hits, const rtk_dev_filter *filter, const rtk_trace_opts *opts, void *stream);
+int rtk_dev_trace_rays_any_filtered(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	uint8_t *d_occluded, const rtk_dev_filter *filter, const rtk_trace_opts *opts, void *stream);
+/* Waits for `stream` and reports whether a launch of this scene on it overflowed a traversal stack
+ * (RTK_AMD_ERR_BAD_SCENE; impossible for a validated tree -- the push is dropped, never written out of bounds). */
+int rtk_dev_trace_status(const rtk_dev_scene *ds, void *stream);
+
 /* Same result as rtk_dev_trace_rays, plus visit counts. Synchronous; not for timing. */
 int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_trace_counters *out);
@@ -133,8 +191,16 @@ int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk_ray *d_ray
  * Closest hits of n rays against a scene blob. hits[i] is written where the ray hit
  * (left untouched on a miss, like rtk_trace_ray); hit_mask[i] (optional) gets 0/1.
  * Returns the number of hits, or (size_t)-1 on error. The device copy of the blob is
- * cached per scene pointer until rtk_free_scene / rtk_amd_forget_scene. */
+ * cached per scene pointer until rtk_free_scene / rtk_amd_forget_scene; every lookup re-checks a
+ * fingerprint of the blob, so a different blob placed at the same address is uploaded afresh. A blob in
+ * caller-owned memory (rtk_finish_build_to, or loaded from disk) keeps its device copy until
+ * rtk_amd_forget_scene is called for it. Each calling thread uses its own stream and staging buffers. */
 size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask);
+/* Batch form of rtk_trace_ray_filter (rtk.h:130) with a host callback: per ray the closest candidate that
+ * `filter` accepts. Every candidate of a ray is offered, in increasing (t, primitive id) order, until one is
+ * accepted; the batch runs in rounds (one launch per round, not per candidate). */
+size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask,
+	rtk_filter_fn *filter, void *filter_user);
 void rtk_amd_forget_scene(const rtk_scene *scene);
 
 #ifdef __cplusplus

@@ -27,6 +27,15 @@ class Counters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class Filter(C.Structure):
+    _fields_ = [("mesh_mask", C.c_void_p), ("mesh_mask_bits", C.c_uint32), ("ignore_mesh", C.c_void_p),
+                ("ignore_tri", C.c_void_p), ("after_t", C.c_void_p), ("after_mesh", C.c_void_p),
+                ("after_tri", C.c_void_p), ("callback", C.c_void_p), ("user", C.c_void_p)]
+
+
+FILTER_CB = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
 def build_oracle(force=False):
     """Compile the C restatement (and the reference shim when /root/reference is present)."""
     if force or not os.path.exists(ORACLE_SO) or \
@@ -60,6 +69,8 @@ def lib():
         L.ora_validate_blob.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ora_max_threads.restype = C.c_int
+        L.ora_trace_rays_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.POINTER(Filter)]
         _lib = L
     return _lib
 
@@ -149,6 +160,47 @@ def trace(blob, rays, ties=TIES_CANONICAL, threads=None, counters=False):
                          threads or default_threads(), C.byref(ctr) if counters else None)
     if counters:
         return hits, mask.astype(bool), ctr.as_dict()
+    return hits, mask.astype(bool)
+
+
+def trace_filtered(blob, rays, mesh_mask=None, ignore=None, after=None, callback=None, threads=None):
+    """Closest candidate accepted by the filters (oracle statement of rtk_dev_filter / rtk_trace_rays_filter).
+
+    mesh_mask: bools per mesh; ignore: (mesh[n], tri[n]) uint32 arrays; after: (t[n], mesh[n], tri[n]) with mesh
+    0xffffffff = off; callback(ray_index, hit_record) -> bool (HIT_DTYPE scalar)."""
+    rays = np.ascontiguousarray(rays)
+    assert rays.dtype == RAY_DTYPE
+    n = rays.shape[0]
+    hits = np.zeros(n, dtype=HIT_DTYPE)
+    mask = np.zeros(n, dtype=np.uint8)
+    f = Filter()
+    keep = []
+    if mesh_mask is not None:
+        bits = np.asarray(mesh_mask, bool)
+        words = np.zeros((len(bits) + 31) // 32, np.uint32)
+        for m, b in enumerate(bits):
+            if b:
+                words[m >> 5] |= np.uint32(1 << (m & 31))
+        keep.append(words)
+        f.mesh_mask, f.mesh_mask_bits = words.ctypes.data, len(bits)
+    if ignore is not None:
+        im, it = (np.ascontiguousarray(a, np.uint32) for a in ignore)
+        keep += [im, it]
+        f.ignore_mesh, f.ignore_tri = im.ctypes.data, it.ctypes.data
+    if after is not None:
+        at = np.ascontiguousarray(after[0], np.float32)
+        am, ai = (np.ascontiguousarray(a, np.uint32) for a in after[1:])
+        keep += [at, am, ai]
+        f.after_t, f.after_mesh, f.after_tri = at.ctypes.data, am.ctypes.data, ai.ctypes.data
+    if callback is not None:
+        def cb(user, i, hit_ptr):
+            h = np.ctypeslib.as_array((C.c_uint8 * 68).from_address(hit_ptr)).view(HIT_DTYPE)[0]
+            return bool(callback(int(i), h))
+        fn = FILTER_CB(cb)
+        keep.append(fn)
+        f.callback = C.cast(fn, C.c_void_p)
+    lib().ora_trace_rays_filter(blob.ptr, rays.ctypes.data, n, hits.ctypes.data, mask.ctypes.data,
+                                threads or default_threads(), C.byref(f))
     return hits, mask.astype(bool)
 
 

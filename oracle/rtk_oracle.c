@@ -84,7 +84,26 @@ typedef struct {
 	float sh[3];          /* shear constants                rtk.c:561-563 */
 	uint32_t sign_mask;
 	ora_counters *ctr;
+	const ora_filter *filter;   /* optional candidate filter (rtk.h:117 semantics), canonical ties only */
+	size_t ray_index;
 } ora_trace;
+
+static inline bool id_less(uint32_t mesh_a, uint32_t tri_a, uint32_t mesh_b, uint32_t tri_b);
+
+/* Does the filter let this candidate through? Mirrors rtk_dev_filter of include/rtk_amd.h. */
+static bool filter_accepts(const ora_trace *rt, uint32_t mesh, uint32_t tri, float t, const rtk_hit *cand)
+{
+	const ora_filter *f = rt->filter;
+	const size_t i = rt->ray_index;
+	if (f->mesh_mask && !(mesh < f->mesh_mask_bits && ((f->mesh_mask[mesh >> 5] >> (mesh & 31u)) & 1u))) return false;
+	if (f->ignore_mesh && f->ignore_mesh[i] == mesh && f->ignore_tri[i] == tri) return false;
+	if (f->after_t && f->after_mesh[i] != 0xffffffffu) {
+		const float at = f->after_t[i];
+		if (!(t > at || (t == at && id_less(f->after_mesh[i], f->after_tri[i], mesh, tri)))) return false;
+	}
+	if (f->callback && !f->callback(f->user, i, cand)) return false;
+	return true;
+}
 
 /* rtk.c:550-566. kz is the FIRST axis whose |d| equals the maximum (x, then y,
  * then z); the sign mask uses sign BITS, so -0.0f counts as negative (rtk.c:152-154). */
@@ -209,6 +228,14 @@ static void leaf_visit(ora_trace *rt, uint64_t leaf_ptr)
 							rt->hit.mesh_index, rt->hit.triangle_index);
 					}
 				}
+			}
+			if (accept && rt->filter) {
+				rtk_hit cand;
+				cand.t = t; cand.u = u[l] * rcp_det; cand.v = v[l] * rcp_det;
+				cand.vertex[0] = verts[tri->v[0]]; cand.vertex[1] = verts[tri->v[1]]; cand.vertex[2] = verts[tri->v[2]];
+				cand.mesh_index = mesh_table[tri->local_mesh];
+				cand.triangle_index = tri->triangle_index;
+				accept = filter_accepts(rt, cand.mesh_index, cand.triangle_index, t, &cand);
 			}
 			if (accept) {
 				/* rtk.c:372-381 */
@@ -396,6 +423,38 @@ void ora_trace_rays(const void *blob, const rtk_ray *rays, size_t n, rtk_hit *hi
 		}
 	}
 	if (total) *total = sum;
+}
+
+/* Canonical ties; the filter is asked about a candidate exactly when it would become the new closest hit, so
+ * the result is the closest candidate the filter accepts (the order of the questions depends on the BVH, the
+ * answer does not, as long as the filter is a function of the candidate). */
+void ora_trace_rays_filter(const void *blob, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *mask,
+	int threads, const ora_filter *filter)
+{
+	if (threads < 1) threads = 1;
+	if (filter && filter->callback) threads = 1;   /* callbacks may come from an interpreter */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+#endif
+	for (long long i = 0; i < (long long)n; i++) {
+		ora_trace rt;
+		const rtk_ray *ray = &rays[i];
+		memset(&rt, 0, sizeof(rt));
+		rt.blob = (const char *)blob;
+		rt.ray = *ray;
+		rt.hit.t = ray->max_t;
+		rt.ties = ORA_TIES_CANONICAL;
+		rt.filter = filter;
+		rt.ray_index = (size_t)i;
+		ora_ray_setup(ray, rt.k, rt.sh, &rt.sign_mask);
+		rt.so[0] = ray->origin.v[rt.k[0]];
+		rt.so[1] = ray->origin.v[rt.k[1]];
+		rt.so[2] = ray->origin.v[rt.k[2]];
+		bvh_traverse(&rt, ORA_ROOT_OFFSET);
+		/* with a filter "found" (not t < max_t) says whether a candidate was accepted */
+		if (rt.found && hits) hits[i] = rt.hit;
+		if (mask) mask[i] = rt.found ? 1 : 0;
+	}
 }
 
 void ora_trace_chain(const void *const *blobs, size_t num_blobs, const rtk_ray *rays, size_t n,

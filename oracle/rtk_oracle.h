@@ -60,6 +60,24 @@ bool ora_trace_ray(const void *blob, const rtk_ray *ray, rtk_hit *hit, int ties,
 void ora_trace_rays(const void *blob, const rtk_ray *rays, size_t n, rtk_hit *hits,
 	uint8_t *mask, int ties, int threads, ora_counters *total);
 
+/* Candidate filters, the oracle's statement of what include/rtk_amd.h's rtk_dev_filter / rtk_trace_rays_filter
+ * mean (reference: rtk_filter_fn rtk.h:117, stub rtk.c:579-582): a candidate is considered only if every filter
+ * that is set lets it through; per-ray arrays are indexed by the ray's position in the batch. */
+typedef bool ora_filter_fn(void *user, size_t ray_index, const rtk_hit *candidate);
+typedef struct ora_filter {
+	const uint32_t *mesh_mask;      /* bit m set = mesh m visible */
+	uint32_t mesh_mask_bits;
+	const uint32_t *ignore_mesh;    /* per ray: (mesh, triangle) never a candidate; NULL = none */
+	const uint32_t *ignore_tri;
+	const float *after_t;           /* per ray: only candidates after (t, mesh, triangle); mesh 0xffffffff = off */
+	const uint32_t *after_mesh;
+	const uint32_t *after_tri;
+	ora_filter_fn *callback;
+	void *user;
+} ora_filter;
+void ora_trace_rays_filter(const void *blob, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *mask,
+	int threads, const ora_filter *filter);
+
 /* Leaf chain: trace every ray against `num_blobs` blobs in order, feeding
  * ray.max_t = best.t after each hit. */
 void ora_trace_chain(const void *const *blobs, size_t num_blobs, const rtk_ray *rays, size_t n,

@@ -35,10 +35,28 @@ class SceneInfo(C.Structure):
         return {k: (float(getattr(self, k)) if k == "build_ms" else int(getattr(self, k))) for k, _ in self._fields_}
 
 
+class SceneCheck(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "nodes_checked", "leaves_checked", "triangles_checked", "box_violations", "loose_boxes", "bad_references",
+        "leaf_format_errors", "triangles_missing", "triangles_duplicated", "nodes_unreachable", "nodes_shared",
+        "primitive_id_errors", "first_bad_index", "content_hash")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class TraceOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("image_width", C.c_uint32),
                 ("image_height", C.c_uint32), ("refill_min", C.c_uint32), ("blocks_per_cu", C.c_uint32),
                 ("node_exit", C.c_uint32)]
+
+
+class DevFilter(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("mesh_mask_bits", C.c_uint32), ("d_mesh_mask", C.c_void_p),
+                ("d_ignore_prim", C.c_void_p), ("d_after", C.c_void_p)]
+
+
+FILTER_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_void_p)   # rtk_filter_fn (rtk.h:117)
 
 
 class TraceCounters(C.Structure):
@@ -57,7 +75,10 @@ RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_
                      "rtk_dev_scene_upload", "rtk_dev_scene_build", "rtk_dev_scene_free", "rtk_dev_scene_get_info",
                      "rtk_dev_scene_mesh_base", "rtk_dev_scene_primitive_order", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
                      "rtk_dev_trace_rays", "rtk_dev_trace_rays_any", "rtk_dev_expand_hits",
-                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_trace_rays", "rtk_amd_forget_scene"]
+                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_trace_rays", "rtk_amd_forget_scene",
+                     "rtk_dev_scene_validate", "rtk_amd_release_workspace", "rtk_dev_scene_upload_buffer",
+                     "rtk_dev_trace_rays_filtered", "rtk_dev_trace_rays_any_filtered", "rtk_dev_trace_status",
+                     "rtk_trace_rays_filter"]
 
 _lib = None
 
@@ -100,6 +121,19 @@ def lib():
     L.rtk_trace_rays.restype = C.c_size_t
     L.rtk_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.rtk_amd_forget_scene.argtypes = [C.c_void_p]
+    L.rtk_dev_scene_validate.argtypes = [C.c_void_p, C.POINTER(SceneCheck)]
+    L.rtk_dev_scene_upload_buffer.restype = C.c_void_p
+    L.rtk_dev_scene_upload_buffer.argtypes = [C.c_void_p, C.c_size_t]
+    L.rtk_dev_trace_rays_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(DevFilter),
+                                              C.POINTER(TraceOpts), C.c_void_p]
+    L.rtk_dev_trace_rays_any_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(DevFilter),
+                                                  C.POINTER(TraceOpts), C.c_void_p]
+    L.rtk_dev_trace_status.argtypes = [C.c_void_p, C.c_void_p]
+    L.rtk_trace_rays_filter.restype = C.c_size_t
+    L.rtk_trace_rays_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtk_trace_ray_filter.restype = C.c_bool
+    L.rtk_trace_ray_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtk_amd_release_workspace.restype = None
     L.rtk_build_scene.restype = C.c_void_p
     L.rtk_build_scene.argtypes = [C.POINTER(SceneDesc)]
     L.rtk_free_scene.argtypes = [C.c_void_p]
@@ -172,10 +206,10 @@ class DeviceScene:
         """blob: bytes-like / numpy uint8 / object with .ptr -- a scene blob in rtk format."""
         _torch()
         if hasattr(blob, "ptr"):
-            return cls(lib().rtk_dev_scene_upload(C.c_void_p(blob.ptr)), blob)
+            return cls(lib().rtk_dev_scene_upload_buffer(C.c_void_p(blob.ptr), blob.size), blob)
         arr = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
         arr = np.ascontiguousarray(arr)
-        return cls(lib().rtk_dev_scene_upload(C.c_void_p(arr.ctypes.data)), arr)
+        return cls(lib().rtk_dev_scene_upload_buffer(C.c_void_p(arr.ctypes.data), arr.size), arr)
 
     @classmethod
     def build(cls, meshes):
@@ -199,6 +233,14 @@ class DeviceScene:
         i = SceneInfo()
         _check(lib().rtk_dev_scene_get_info(self.handle, C.byref(i)), "rtk_dev_scene_get_info")
         return i.as_dict()
+
+    def validate(self):
+        """Device-side structural check; returns (ok, counts dict)."""
+        c = SceneCheck()
+        rc = lib().rtk_dev_scene_validate(self.handle, C.byref(c))
+        if rc not in (0, -5):
+            raise RtkError("rtk_dev_scene_validate failed (%d): %s" % (rc, last_error()))
+        return rc == 0, c.as_dict()
 
     def mesh_base(self):
         n = self.info()["num_meshes"] + 1
@@ -272,6 +314,46 @@ class DeviceScene:
         mask = d_mask.cpu().numpy().astype(bool)
         return hits, mask, rec
 
+    def trace_filtered(self, rays, mesh_mask=None, ignore_prim=None, after=None, any_hit=False, opts=None):
+        """Built-in device filters (rtk_dev_filter). mesh_mask: iterable of bools per mesh; ignore_prim: uint32 per
+        ray; after: HIT_RECORD_DTYPE per ray. Returns records (closest) or an occluded bool array (any_hit)."""
+        torch = _torch()
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        d_rays = to_device(rays)
+        f = DevFilter()
+        f.struct_size = C.sizeof(DevFilter)
+        keep = []
+        if mesh_mask is not None:
+            bits = np.asarray(mesh_mask, bool)
+            words = np.zeros((len(bits) + 31) // 32, np.uint32)
+            for m, b in enumerate(bits):
+                if b:
+                    words[m >> 5] |= np.uint32(1 << (m & 31))
+            d = to_device(words); keep.append(d)
+            f.d_mesh_mask, f.mesh_mask_bits = d.data_ptr(), len(bits)
+        if ignore_prim is not None:
+            d = to_device(np.ascontiguousarray(ignore_prim, np.uint32)); keep.append(d)
+            f.d_ignore_prim = d.data_ptr()
+        if after is not None:
+            a = np.ascontiguousarray(after)
+            assert a.dtype == HIT_RECORD_DTYPE and a.shape[0] == n
+            d = to_device(a); keep.append(d)
+            f.d_after = d.data_ptr()
+        if any_hit:
+            d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+            _check(lib().rtk_dev_trace_rays_any_filtered(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_out.data_ptr()),
+                                                         C.byref(f), C.byref(opts) if opts is not None else None, _stream_ptr()),
+                   "rtk_dev_trace_rays_any_filtered")
+            _check(lib().rtk_dev_trace_status(self.handle, _stream_ptr()), "rtk_dev_trace_status")
+            return d_out.cpu().numpy().astype(bool)
+        d_out = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+        _check(lib().rtk_dev_trace_rays_filtered(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_out.data_ptr()),
+                                                 C.byref(f), C.byref(opts) if opts is not None else None, _stream_ptr()),
+               "rtk_dev_trace_rays_filtered")
+        _check(lib().rtk_dev_trace_status(self.handle, _stream_ptr()), "rtk_dev_trace_status")
+        return d_out.cpu().numpy().view(HIT_RECORD_DTYPE)
+
     def trace_any(self, rays, opts=None):
         rays = np.ascontiguousarray(rays)
         n = rays.shape[0]
@@ -333,6 +415,26 @@ def trace_ray(scene_ptr, ray):
     h = np.zeros(1, HIT_DTYPE)
     ok = lib().rtk_trace_ray(C.c_void_p(scene_ptr), r.ctypes.data, h.ctypes.data)
     return h[0] if ok else None
+
+
+def trace_rays_filter(scene_ptr, rays, accept):
+    """rtk_trace_rays_filter with a Python callback accept(ray_index, hit) -> bool; hit is a HIT_DTYPE record."""
+    _torch()
+    rays = np.ascontiguousarray(rays)
+    n = rays.shape[0]
+    hits = np.zeros(n, HIT_DTYPE)
+    mask = np.zeros(n, np.uint8)
+    base = rays.ctypes.data
+
+    def cb(user, ray_ptr, hit_ptr):
+        h = np.ctypeslib.as_array((C.c_uint8 * 68).from_address(hit_ptr)).view(HIT_DTYPE)[0]
+        return bool(accept((ray_ptr - base) // 32, h))
+    fn = FILTER_FN(cb)
+    r = lib().rtk_trace_rays_filter(C.c_void_p(scene_ptr), rays.ctypes.data, n, hits.ctypes.data, mask.ctypes.data,
+                                    C.cast(fn, C.c_void_p), None)
+    if r == C.c_size_t(-1).value:
+        raise RtkError("rtk_trace_rays_filter failed: " + last_error())
+    return hits, mask.astype(bool)
 
 
 def trace_rays(scene_ptr, rays):

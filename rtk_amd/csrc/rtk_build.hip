@@ -158,7 +158,7 @@ __device__ __forceinline__ unsigned long long spread21(uint32_t v)
 	return x;
 }
 
-__global__ void k_morton(const float *in_pos, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals)
+__global__ void k_morton(const float *in_pos, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals, uint32_t drop_bits)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -174,7 +174,7 @@ __global__ void k_morton(const float *in_pos, uint32_t n, const uint32_t *bounds
 		uint32_t v = (uint32_t)(t * 2097152.0f);
 		q[a] = v > 2097151u ? 2097151u : v;
 	}
-	keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+	keys[i] = ((spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2])) >> drop_bits;   // most significant bits only
 	vals[i] = i;
 }
 
@@ -361,18 +361,18 @@ __global__ void k_emit_tris(const float *in_pos, const uint32_t *in_vidx, const 
 	if (s >= n) return;
 	const uint32_t g = vals[s];
 	const float *p = in_pos + 9 * (size_t)g;
+	// mesh of global primitive g: last m with mesh_base[m] <= g
+	uint32_t lo = 0, hi = num_meshes;
+	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
 	DevTri t;
 	t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2]; t.prim = g;
-	t.v1[0] = p[3]; t.v1[1] = p[4]; t.v1[2] = p[5]; t.flags = 0u;
+	t.v1[0] = p[3]; t.v1[1] = p[4]; t.v1[2] = p[5]; t.flags = lo << 8;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
 	t.v2[0] = p[6]; t.v2[1] = p[7]; t.v2[2] = p[8]; t.spare = 0u;
 	tris[s] = t;
 	vertex_index[3 * (size_t)s + 0] = in_vidx[3 * (size_t)g + 0];
 	vertex_index[3 * (size_t)s + 1] = in_vidx[3 * (size_t)g + 1];
 	vertex_index[3 * (size_t)s + 2] = in_vidx[3 * (size_t)g + 2];
 	prim_slot[g] = s;
-	// mesh of global primitive g: last m with mesh_base[m] <= g
-	uint32_t lo = 0, hi = num_meshes;
-	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
 	slot_mesh[s] = lo;
 	slot_tri[s] = g - (uint32_t)mesh_base[lo];
 }
@@ -387,9 +387,8 @@ __device__ __forceinline__ int delta(const unsigned long long *keys, int n, int 
 	return __clzll((long long)(a ^ b));
 }
 
-// children: >= 0 inner node index, < 0 leaf ~index
-__global__ void k_karras(const unsigned long long *keys, int n, int *left, int *right, int *parent_inner, int *parent_leaf,
-	uint32_t *range_first, uint32_t *range_last)
+// children: >= 0 inner node index, < 0 leaf ~index. lr[i] = (left, right), range[i] = (first, last) sorted leaf covered.
+__global__ void k_karras(const unsigned long long *keys, int n, int2 *lr, uint2 *range, int *parent_inner, int *parent_leaf)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n - 1) return;
@@ -412,10 +411,8 @@ __global__ void k_karras(const unsigned long long *keys, int n, int *left, int *
 	const int lo = i < j ? i : j, hi = i < j ? j : i;
 	const int lc = lo == gamma ? ~gamma : gamma;
 	const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
-	left[i] = lc;
-	right[i] = rc;
-	range_first[i] = (uint32_t)lo;
-	range_last[i] = (uint32_t)hi;
+	lr[i] = make_int2(lc, rc);
+	range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);
 	if (lc >= 0) parent_inner[lc] = i; else parent_leaf[~lc] = i;
 	if (rc >= 0) parent_inner[rc] = i; else parent_leaf[~rc] = i;
 	if (i == 0) parent_inner[0] = -1;
@@ -439,12 +436,86 @@ __device__ __forceinline__ void tri_box(const DevTri *tris, uint32_t s, float mn
 	}
 }
 
-// One thread per sorted triangle walks towards the root; the second thread to arrive at a
-// node owns it. The hand-off of the first arriver's 32-byte record has to cross CUs and XCDs
-// (per-CU L1 and per-XCD L2 are not coherent with each other). An acq_rel arrival counter does
-// that with a cache write-back + invalidate per wave per level (39 ms of a 10M-triangle build);
-// instead the record itself travels as four 8-byte device-scope atomics, which execute at the
-// memory side and are therefore coherent everywhere, and the arrival counter stays relaxed.
+// Record of a single sorted triangle seen as a subtree.
+__device__ __forceinline__ BinNode leaf_record(const DevTri *tris, uint32_t s, const BuildParams &bp)
+{
+	BinNode b;
+	tri_box(tris, s, b.mn, b.mx);
+	b.cnt_flag = 1u;
+	b.cost = bp.cost_tri * half_area(b.mn, b.mx);
+	return b;
+}
+
+// Record of an inner node from the records of its two children: box union, triangle count and the SAH
+// decision "one leaf of cnt triangles" vs "split" (cost model of rtk.c:931-949 with working constants,
+// SURVEY.md appendix B9). min/max/+ are commutative, so the result does not depend on which child is a.
+__device__ __forceinline__ BinNode combine_records(const BinNode &a, const BinNode &b, const BuildParams &bp)
+{
+	BinNode out;
+#pragma unroll
+	for (int k = 0; k < 3; k++) { out.mn[k] = fminf(a.mn[k], b.mn[k]); out.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+	const uint32_t cnt = (a.cnt_flag & 0x7fffffffu) + (b.cnt_flag & 0x7fffffffu);
+	const float cost = a.cost + b.cost;
+	const float area = half_area(out.mn, out.mx);
+	const float split = bp.cost_node * area + cost;
+	const float leaf = cnt <= bp.max_leaf ? bp.cost_tri * (float)cnt * area : INFINITY;
+	out.cnt_flag = cnt | (leaf <= split ? 0x80000000u : 0u);
+	out.cost = fminf(leaf, split);
+	return out;
+}
+
+// Pass 1, tile-local. The sorted triangles are cut into tiles of REFIT_TILE; one workgroup owns a tile
+// and finishes every inner node whose whole range lies inside it. Such a node has its own index inside
+// the tile too (a Karras node is an end point of its range), so arrival counters and node records of the
+// tile live in LDS: the hand-off between the two threads that meet at a node never leaves the CU, which
+// is what made the all-global version cost ~14 memory-side atomics per node (3.8 ms at 10M triangles).
+// Finished records are written out once, coalesced. A thread that reaches a node whose range leaves the
+// tile stops and notes that node in cont[] for pass 2.
+#define REFIT_TILE 1024
+#define REFIT_BLOCK 256
+
+__global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const int2 *lr, const uint2 *range,
+	const int *parent_inner, const int *parent_leaf, BinNode *bin, int *cont, BuildParams bp)
+{
+	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
+	__shared__ uint32_t s_arrive[REFIT_TILE];  // 4 KB
+	const int lo = (int)blockIdx.x * REFIT_TILE;
+	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
+	for (int k = threadIdx.x; k < REFIT_TILE; k += REFIT_BLOCK) s_arrive[k] = 0u;
+	__syncthreads();
+	for (int k = 0; k < REFIT_TILE / REFIT_BLOCK; k++) {
+		const int i = lo + k * REFIT_BLOCK + (int)threadIdx.x;
+		if (i > hi) continue;
+		BinNode cur = leaf_record(tris, (uint32_t)i, bp);
+		int cur_ref = ~i;
+		int node = parent_leaf[i];
+		int resume = -1;                        // node at which pass 2 continues for this thread, -1: none
+		while (node >= 0) {
+			const uint2 r = range[node];
+			if ((int)r.x < lo || (int)r.y > hi) { resume = node; break; }
+			if (cur_ref >= 0) s_bin[cur_ref - lo] = cur;          // published before the arrival below (LDS is in order)
+			const uint32_t old = __hip_atomic_fetch_add(&s_arrive[node - lo], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (old == 0u) { cur_ref = -1 - n; break; }            // first arriver: the sibling's thread carries on
+			const int2 c = lr[node];
+			const int sib = c.x == cur_ref ? c.y : c.x;
+			const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : s_bin[sib - lo];
+			cur = combine_records(cur, other, bp);
+			cur_ref = node;
+			node = parent_inner[node];
+		}
+		if (cur_ref >= 0) s_bin[cur_ref - lo] = cur;              // finished subtree whose parent is outside the tile (or the root)
+		cont[i] = resume;
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < REFIT_TILE; k += REFIT_BLOCK)
+		if (s_arrive[k] == 2u) bin[lo + k] = s_bin[k];
+}
+
+// Pass 2: the few nodes whose range crosses a tile boundary (about two per tile plus chains). The
+// hand-off of the first arriver's 32-byte record has to cross CUs and XCDs here (per-CU L1 and per-XCD
+// L2 are not coherent with each other): the record travels as four 8-byte device-scope atomics, which
+// execute at the memory side and are therefore coherent everywhere, and the arrival counter stays
+// relaxed. Records written by pass 1 are plain stores made visible by the kernel boundary.
 __device__ __forceinline__ void bin_store(BinNode *dst, const BinNode &v)
 {
 	unsigned long long *d = reinterpret_cast<unsigned long long *>(dst);
@@ -469,138 +540,212 @@ __device__ __forceinline__ BinNode bin_load(BinNode *src)
 	return v;
 }
 
-__global__ void k_refit(const DevTri *tris, int n, const int *left, const int *right, const int *parent_inner,
-	const int *parent_leaf, uint32_t *arrive, BinNode *bin, BuildParams bp)
+__global__ void k_refit_top(const DevTri *tris, int n, const int2 *lr, const int *parent_inner, const int *cont,
+	uint32_t *arrive, BinNode *bin, BuildParams bp)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	int node = parent_leaf[i];
+	int node = cont[i];
 	while (node >= 0) {
 		// every record this thread published is complete at the memory side before it announces itself
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		const uint32_t old = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (old == 0u) return;
-		float mn[3], mx[3], cost = 0.0f;
-		uint32_t cnt = 0;
-		for (int side = 0; side < 2; side++) {
-			const int c = side == 0 ? left[node] : right[node];
-			float cmn[3], cmx[3], ccost;
-			uint32_t ccnt;
-			if (c < 0) {
-				tri_box(tris, (uint32_t)~c, cmn, cmx);
-				ccnt = 1u;
-				ccost = bp.cost_tri * half_area(cmn, cmx);
-			} else {
-				const BinNode b = bin_load(&bin[c]);
-				cmn[0] = b.mn[0]; cmn[1] = b.mn[1]; cmn[2] = b.mn[2];
-				cmx[0] = b.mx[0]; cmx[1] = b.mx[1]; cmx[2] = b.mx[2];
-				ccnt = b.cnt_flag & 0x7fffffffu;
-				ccost = b.cost;
-			}
-			if (side == 0) { for (int a = 0; a < 3; a++) { mn[a] = cmn[a]; mx[a] = cmx[a]; } }
-			else { for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], cmn[a]); mx[a] = fmaxf(mx[a], cmx[a]); } }
-			cnt += ccnt;
-			cost += ccost;
-		}
-		const float area = half_area(mn, mx);
-		const float split = bp.cost_node * area + cost;
-		const float leaf = cnt <= bp.max_leaf ? bp.cost_tri * (float)cnt * area : INFINITY;
-		BinNode out;
-		out.mn[0] = mn[0]; out.mn[1] = mn[1]; out.mn[2] = mn[2];
-		out.mx[0] = mx[0]; out.mx[1] = mx[1]; out.mx[2] = mx[2];
-		out.cnt_flag = cnt | (leaf <= split ? 0x80000000u : 0u);
-		out.cost = fminf(leaf, split);
-		bin_store(&bin[node], out);
+		const int2 c = lr[node];
+		const BinNode a = c.x < 0 ? leaf_record(tris, (uint32_t)~c.x, bp) : bin_load(&bin[c.x]);
+		const BinNode b = c.y < 0 ? leaf_record(tris, (uint32_t)~c.y, bp) : bin_load(&bin[c.y]);
+		bin_store(&bin[node], combine_records(a, b, bp));
 		node = parent_inner[node];
 	}
 }
 
 // ---------------------------------------------------------------------------------- 8 collapse
+// Binary tree -> 128 B 4-wide nodes, breadth first, one level at a time. A job is one wide node = one
+// binary node that gets opened: its two children, then twice more the largest-area child that is still
+// an inner node (the reference collapses exactly two binary levels, rtk.c:1572-1592; the greedy rule
+// costs 2 % fewer node visits on the benchmark scene). Wide-node numbers come from prefix sums, not from
+// an atomic counter, so the node array is the same for every build of the same input:
+//   k_collapse_decide  per job: the (up to four) children and how many of them are wide nodes themselves
+//   k_collapse_scan    exclusive scan of the per-256-job sums (one workgroup)
+//   k_collapse_emit    per job: write the 128 B node; its inner children become the next level's jobs
+// The level sizes live in device memory (LevelState); the host only reads them back every few levels.
+#define COLLAPSE_BLOCK 256
 
-struct WideJob { int bin; uint32_t wide; };
+struct LevelState {
+	uint32_t count[2];        // jobs of level L at [L & 1]
+	uint32_t base[2];         // wide-node index of the first job of level L at [L & 1]
+	uint32_t total_nodes;
+	uint32_t depth;
+	uint32_t pad[2];
+};
 
 struct Cand {
 	int ref;          // binary child: >= 0 inner, < 0 leaf ~slot
-	float mn[3], mx[3];
 	float area;       // > 0 only if the child may still be opened
 };
 
-__device__ __forceinline__ void load_cand(Cand &c, int ref, const DevTri *tris, const BinNode *bin)
+__device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin)
 {
+	Cand c;
 	c.ref = ref;
-	if (ref < 0) {
-		tri_box(tris, (uint32_t)~ref, c.mn, c.mx);
-		c.area = -1.0f;
-	} else {
+	c.area = -1.0f;
+	if (ref >= 0) {
 		const BinNode b = bin[ref];
-		c.mn[0] = b.mn[0]; c.mn[1] = b.mn[1]; c.mn[2] = b.mn[2];
-		c.mx[0] = b.mx[0]; c.mx[1] = b.mx[1]; c.mx[2] = b.mx[2];
-		c.area = (b.cnt_flag & 0x80000000u) ? -1.0f : half_area(c.mn, c.mx);
+		if (!(b.cnt_flag & 0x80000000u)) c.area = half_area(b.mn, b.mx);
+	}
+	return c;
+}
+
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *jobs, const LevelState *st, uint32_t level, const int2 *lr,
+	const BinNode *bin, int4 *dec, uint32_t *info, uint32_t *block_sums)
+{
+	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
+	const uint32_t count = st->count[level & 1u];
+	for (uint32_t vb = blockIdx.x; vb * COLLAPSE_BLOCK < count; vb += gridDim.x) {
+		const uint32_t j = vb * COLLAPSE_BLOCK + threadIdx.x;
+		uint32_t n_inner = 0;
+		if (j < count) {
+			const int b = jobs[j];
+			Cand c[4];
+			int nc;
+			if (bin[b].cnt_flag & 0x80000000u) {
+				// the whole (sub)tree is one leaf: only the root of a tiny scene
+				c[0].ref = b; c[0].area = -1.0f;
+				nc = 1;
+			} else {
+				const int2 ch = lr[b];
+				c[0] = make_cand(ch.x, bin);
+				c[1] = make_cand(ch.y, bin);
+				nc = 2;
+				for (int round = 0; round < 2; round++) {
+					int best = -1;
+					float best_area = 0.0f;
+					for (int k = 0; k < nc; k++) if (c[k].area > best_area) { best_area = c[k].area; best = k; }
+					if (best < 0) break;
+					const int2 o = lr[c[best].ref];
+					c[best] = make_cand(o.x, bin);
+					c[nc] = make_cand(o.y, bin);
+					nc++;
+				}
+			}
+			uint32_t mask = 0;
+			int r[4] = { 0, 0, 0, 0 };
+			for (int k = 0; k < nc; k++) {
+				r[k] = c[k].ref;
+				if (c[k].area > 0.0f) { mask |= 1u << k; n_inner++; }
+			}
+			dec[j] = make_int4(r[0], r[1], r[2], r[3]);
+			info[j] = (uint32_t)nc | (mask << 4) | (n_inner << 8);
+		}
+		uint32_t sum = n_inner;
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+		if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = sum;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t t = 0;
+			for (int w = 0; w < COLLAPSE_BLOCK / 64; w++) t += s_w[w];
+			block_sums[vb] = t;
+		}
+		__syncthreads();
 	}
 }
 
-// One thread per 4-wide node of this level: open the binary node, then twice more open
-// the largest-area child that is still an inner node, and write the 128 B node. Inner
-// children get their indices from an atomic counter and go to the next level's queue.
-__global__ void k_collapse_level(const WideJob *jobs, uint32_t num_jobs, const int *left, const int *right,
-	const uint32_t *range_first, const uint32_t *range_last, const BinNode *bin, DevTri *tris, DevNode *nodes,
-	WideJob *next_jobs, uint32_t *next_count, uint32_t next_base)
+// One workgroup: exclusive scan of the block sums of level `level`, and the bookkeeping of the next level.
+__global__ void __launch_bounds__(1024) k_collapse_scan(uint32_t *block_sums, LevelState *st, uint32_t level)
 {
-	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= num_jobs) return;
-	const WideJob job = jobs[j];
-	Cand c[4];
-	int nc;
-	if (bin[job.bin].cnt_flag & 0x80000000u) {
-		// the whole (sub)tree is one leaf: only happens for the root of a tiny scene
-		load_cand(c[0], job.bin, tris, bin);
-		nc = 1;
-	} else {
-		load_cand(c[0], left[job.bin], tris, bin);
-		load_cand(c[1], right[job.bin], tris, bin);
-		nc = 2;
-		for (int round = 0; round < 2; round++) {
-			int best = -1;
-			float best_area = 0.0f;
-			for (int k = 0; k < nc; k++) if (c[k].area > best_area) { best_area = c[k].area; best = k; }
-			if (best < 0) break;
-			const int open = c[best].ref;
-			load_cand(c[best], left[open], tris, bin);
-			load_cand(c[nc], right[open], tris, bin);
-			nc++;
-		}
+	__shared__ uint32_t s_wave[16];
+	__shared__ uint32_t s_carry;
+	const uint32_t count = st->count[level & 1u];
+	const uint32_t nb = (count + COLLAPSE_BLOCK - 1u) / COLLAPSE_BLOCK;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) s_carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < nb; base += 1024u) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < nb ? block_sums[i] : 0u;
+		uint32_t inc = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+		if (lane == 63u) s_wave[wave] = inc;
+		__syncthreads();
+		uint32_t off = s_carry;
+		for (uint32_t w = 0; w < wave; w++) off += s_wave[w];
+		if (i < nb) block_sums[i] = off + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 1023u) s_carry = off + inc;
+		__syncthreads();
 	}
-	DevNode out;
-	for (int k = 0; k < 4; k++) {
-		out.pad[k] = 0;
-		if (k >= nc) {
-			out.bx[0][k] = out.by[0][k] = out.bz[0][k] = +1.0f;   // inverted = never hit (rtk.c:1612-1620)
-			out.bx[1][k] = out.by[1][k] = out.bz[1][k] = -1.0f;
-			out.child[k] = RTK_REF_NONE;
-			continue;
-		}
-		out.bx[0][k] = c[k].mn[0]; out.bx[1][k] = c[k].mx[0];
-		out.by[0][k] = c[k].mn[1]; out.by[1][k] = c[k].mx[1];
-		out.bz[0][k] = c[k].mn[2]; out.bz[1][k] = c[k].mx[2];
-		const int ref = c[k].ref;
-		if (ref < 0) {
-			const uint32_t s = (uint32_t)~ref;
-			tris[s].spare = 1u;
-			tris[s].flags = RTK_TRI_LAST;
-			out.child[k] = RTK_REF_LEAF | s;
-		} else if (bin[ref].cnt_flag & 0x80000000u) {
-			const uint32_t first = range_first[ref], last = range_last[ref];
-			tris[first].spare = last - first + 1u;
-			tris[last].flags = RTK_TRI_LAST;
-			out.child[k] = RTK_REF_LEAF | first;
-		} else {
-			const uint32_t slot = atomicAdd(next_count, 1u);
-			next_jobs[slot].bin = ref;
-			next_jobs[slot].wide = next_base + slot;
-			out.child[k] = next_base + slot;
-		}
+	if (threadIdx.x == 0) {
+		const uint32_t b = st->base[level & 1u];
+		st->count[(level + 1u) & 1u] = s_carry;
+		st->base[(level + 1u) & 1u] = b + count;
+		if (count) { st->total_nodes = b + count; st->depth = level + 1u; }
 	}
-	nodes[job.wide] = out;
+}
+
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_emit(const int *jobs, const LevelState *st, uint32_t level, const uint2 *range,
+	const BinNode *bin, const int4 *dec, const uint32_t *info, const uint32_t *block_offsets, DevTri *tris, DevNode *nodes, int *next_jobs)
+{
+	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
+	const uint32_t count = st->count[level & 1u];
+	const uint32_t base = st->base[level & 1u];
+	const uint32_t next_base = base + count;
+	for (uint32_t vb = blockIdx.x; vb * COLLAPSE_BLOCK < count; vb += gridDim.x) {
+		const uint32_t j = vb * COLLAPSE_BLOCK + threadIdx.x;
+		const uint32_t inf = j < count ? info[j] : 0u;
+		const uint32_t n_inner = inf >> 8;
+		// exclusive scan of n_inner over the 256 jobs of this virtual block
+		const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+		uint32_t inc = n_inner;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+		if (lane == 63u) s_w[wave] = inc;
+		__syncthreads();
+		uint32_t off = block_offsets[vb];
+		for (uint32_t w = 0; w < wave; w++) off += s_w[w];
+		off += inc - n_inner;
+		__syncthreads();
+		if (j >= count) continue;
+		const int4 d = dec[j];
+		const int ref[4] = { d.x, d.y, d.z, d.w };
+		const uint32_t nc = inf & 15u, mask = (inf >> 4) & 15u;
+		DevNode out;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			out.pad[k] = 0;
+			if ((uint32_t)k >= nc) {
+				out.bx[0][k] = out.by[0][k] = out.bz[0][k] = +1.0f;   // inverted = never hit (rtk.c:1612-1620)
+				out.bx[1][k] = out.by[1][k] = out.bz[1][k] = -1.0f;
+				out.child[k] = RTK_REF_NONE;
+				continue;
+			}
+			float mn[3], mx[3];
+			const int r = ref[k];
+			if (r < 0) {
+				const uint32_t s = (uint32_t)~r;
+				tri_box(tris, s, mn, mx);
+				tris[s].spare = 1u;
+				tris[s].flags |= RTK_TRI_LAST;
+				out.child[k] = RTK_REF_LEAF | s;
+			} else {
+				const BinNode b = bin[r];
+				mn[0] = b.mn[0]; mn[1] = b.mn[1]; mn[2] = b.mn[2];
+				mx[0] = b.mx[0]; mx[1] = b.mx[1]; mx[2] = b.mx[2];
+				if (mask & (1u << k)) {
+					next_jobs[off] = r;
+					out.child[k] = next_base + off;
+					off++;
+				} else {
+					const uint2 rg = range[r];
+					tris[rg.x].spare = rg.y - rg.x + 1u;
+					tris[rg.y].flags |= RTK_TRI_LAST;
+					out.child[k] = RTK_REF_LEAF | rg.x;
+				}
+			}
+			out.bx[0][k] = mn[0]; out.bx[1][k] = mx[0];
+			out.by[0][k] = mn[1]; out.by[1][k] = mx[1];
+			out.bz[0][k] = mn[2]; out.bz[1][k] = mx[2];
+		}
+		nodes[base + j] = out;
+	}
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -617,18 +762,6 @@ float env_float(const char *name, float def)
 {
 	const char *s = getenv(name);
 	return s && *s ? (float)atof(s) : def;
-}
-
-bool exclusive_scan_u32(uint32_t *d, size_t n)
-{
-	const size_t per_block = SCAN_BLOCK * SCAN_ITEMS;
-	const size_t blocks = (n + per_block - 1) / per_block;
-	DevBuf<uint32_t> sums;
-	if (!sums.alloc(blocks)) return false;
-	hipLaunchKernelGGL(k_scan_block, dim3((unsigned)blocks), dim3(SCAN_BLOCK), 0, 0, d, n, sums.p);
-	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, 0, sums.p, (uint32_t)blocks);
-	hipLaunchKernelGGL(k_scan_add, dim3((unsigned)blocks), dim3(SCAN_BLOCK), 0, 0, d, n, sums.p);
-	return hipDeviceSynchronize() == hipSuccess;   // sums is freed on return
 }
 
 // Host decode of a mesh that uses callbacks (rtk.c:1030-1033, 1074-1077), 128 triangles per call.
@@ -714,11 +847,13 @@ rtk_dev_scene *build_tiny(const rtk_scene_desc *desc, const std::vector<uint64_t
 		DevTri t;
 		memset(&t, 0, sizeof(t));
 		for (int a = 0; a < 3; a++) { t.v0[a] = pos[a]; t.v1[a] = pos[3 + a]; t.v2[a] = pos[6 + a]; }
-		t.prim = 0; t.flags = RTK_TRI_LAST; t.spare = 1;
+		t.prim = 0; t.spare = 1;
 		h.tris.push_back(t);
 		for (int c = 0; c < 3; c++) h.vertex_index.push_back(vidx[c]);
 		uint32_t mesh = 0;
 		while (mesh + 1 < mesh_base.size() - 1 && mesh_base[mesh + 1] == 0) mesh++;
+		t.flags = RTK_TRI_LAST | (mesh << 8);
+		h.tris.back() = t;
 		h.slot_mesh.push_back(mesh);
 		h.slot_tri.push_back(0);
 		float mn[3], mx[3];
@@ -773,6 +908,76 @@ bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b
 // rtk_dev_scene_build
 // =====================================================================================
 
+namespace {
+
+// All temporaries of a build come out of ONE device allocation per device that is kept between builds
+// (grown on demand, released by rtk_amd_release_workspace): the 25 hipMalloc/hipFree pairs of the first
+// version cost more than the kernels of a 1M-triangle build. Builds on one device are serialised by the
+// mutex; the workspace is only ever touched in stream order on the null stream.
+struct Workspace {
+	std::mutex mutex;
+	char *base = nullptr;
+	size_t cap = 0;
+};
+Workspace g_workspace[RTK_MAX_DEVICES];
+
+struct Arena {
+	char *base;
+	size_t cap, off;
+	template <typename T> T *take(size_t n)
+	{
+		off = (off + 255u) & ~(size_t)255u;
+		T *p = reinterpret_cast<T *>(base + off);
+		off += (n ? n : 1) * sizeof(T);
+		return off <= cap ? p : nullptr;
+	}
+};
+
+size_t padded(size_t bytes) { return ((bytes ? bytes : 1) + 255u) & ~(size_t)255u; }
+
+// How one mesh reaches the ingest kernel.
+struct MeshPlan {
+	bool on_host_decode = false;    // callbacks: decoded on the host, copied as plain positions
+	bool f64 = false;
+	int idx_kind = 0;               // 0 implicit, 1 u16, 2 u32
+	size_t pstride = 0, istride = 0;
+	size_t pbytes = 0, ibytes = 0;  // bytes to upload (0: already device memory / nothing)
+	const char *pos_src = nullptr, *idx_src = nullptr;
+	bool pos_on_device = false, idx_on_device = false;
+};
+
+int cached_cu_count(int device)
+{
+	static std::mutex m;
+	static int cus[RTK_MAX_DEVICES];
+	std::lock_guard<std::mutex> lock(m);
+	if (device < 0 || device >= RTK_MAX_DEVICES) return 256;
+	if (cus[device] == 0) {
+		int v = 0;
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+		cus[device] = v;
+	}
+	return cus[device];
+}
+
+} // namespace
+
+extern "C" void rtk_amd_release_workspace(void)
+{
+	for (int d = 0; d < RTK_MAX_DEVICES; d++) {
+		Workspace &w = g_workspace[d];
+		std::lock_guard<std::mutex> lock(w.mutex);
+		if (!w.base) continue;
+		int cur = 0;
+		(void)hipGetDevice(&cur);
+		(void)hipSetDevice(d);
+		(void)hipFree(w.base);
+		(void)hipSetDevice(cur);
+		w.base = nullptr;
+		w.cap = 0;
+	}
+}
+
 extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 {
 	if (!desc || (!desc->meshes && desc->num_meshes)) { rtk_set_error("rtk_dev_scene_build: NULL scene description"); return nullptr; }
@@ -794,84 +999,132 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	};
 
 	int device = 0;
-	hipDeviceProp_t prop;
 	BUILD_CHECK(hipGetDevice(&device));
-	BUILD_CHECK(hipGetDeviceProperties(&prop, device));
+	if (device < 0 || device >= RTK_MAX_DEVICES) { rtk_set_error("rtk_dev_scene_build: device %d out of range", device); return nullptr; }
+	const int num_cus = cached_cu_count(device);
 
-	// ---- 1 ingest ------------------------------------------------------------------
-	DevBuf<float> in_pos;
-	DevBuf<uint32_t> in_vidx;
-	stage("props");
-	if (!in_pos.alloc(9 * (size_t)n) || !in_vidx.alloc(3 * (size_t)n)) { rtk_set_error("device build: out of device memory"); return nullptr; }
-	stage("alloc-in");
-	std::vector<float> tiny_pos;
-	std::vector<uint32_t> tiny_vidx;
+	// ---- plan the meshes -----------------------------------------------------------------
+	std::vector<MeshPlan> plans(desc->num_meshes);
+	size_t upload_bytes = 0;
 	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
 		const rtk_mesh *m = &desc->meshes[mi];
+		MeshPlan &pl = plans[mi];
 		const size_t nt = m->num_triangles;
 		if (nt == 0) continue;
-		const uint32_t base = (uint32_t)mesh_base[mi];
-		if (m->position_cb || m->index_cb || n < 2) {
-			std::vector<float> pos9(9 * nt);
-			std::vector<uint32_t> vidx3(3 * nt);
-			decode_mesh_on_host(m, pos9.data(), vidx3.data());
-			if (n < 2) { tiny_pos = pos9; tiny_vidx = vidx3; continue; }
-			BUILD_CHECK(hipMemcpy(in_pos.p + 9 * (size_t)base, pos9.data(), pos9.size() * 4, hipMemcpyHostToDevice));
-			BUILD_CHECK(hipMemcpy(in_vidx.p + 3 * (size_t)base, vidx3.data(), vidx3.size() * 4, hipMemcpyHostToDevice));
-			continue;
-		}
+		if (m->position_cb || m->index_cb || n < 2) { pl.on_host_decode = true; continue; }
 		if (!m->position.data) { rtk_set_error("rtk_dev_scene_build: mesh %zu has no positions", mi); return nullptr; }
-		// raw buffers go to the device as they are; the decode runs there
-		const bool f64 = m->position.type == RTK_TYPE_F64;
-		const size_t pstride = m->position.stride ? m->position.stride : (f64 ? 24 : 12);
-		int idx_kind = 0;
-		size_t istride = 0;
+		pl.f64 = m->position.type == RTK_TYPE_F64;
+		pl.pstride = m->position.stride ? m->position.stride : (pl.f64 ? 24 : 12);
+		pl.pos_src = (const char *)m->position.data;
+		pl.pos_on_device = is_device_ptr(m->position.data);
 		uint64_t max_vertex = 3ull * nt - 1;
-		DevBuf<char> d_idx, d_pos;
-		const char *idx_ptr = nullptr, *pos_ptr = nullptr;
-		const bool pos_on_device = is_device_ptr(m->position.data);
 		if (m->index.data) {
 			const bool u16 = m->index.type == RTK_TYPE_U16;
+			// RTK_TYPE_DEFAULT on an index buffer means 32-bit indices (the reference's default index type, rtk.c:1049-1059)
 			if (!u16 && m->index.type != RTK_TYPE_U32 && m->index.type != RTK_TYPE_DEFAULT) { rtk_set_error("rtk_dev_scene_build: bad index type"); return nullptr; }
-			idx_kind = u16 ? 1 : 2;
-			istride = m->index.stride ? m->index.stride : (u16 ? 6 : 12);
-			if (is_device_ptr(m->index.data)) {
-				if (!pos_on_device) { rtk_set_error("rtk_dev_scene_build: mesh %zu has device indices but host positions", mi); return nullptr; }
-				idx_ptr = (const char *)m->index.data;
-			} else {
-				if (!pos_on_device) {
+			pl.idx_kind = u16 ? 1 : 2;
+			pl.istride = m->index.stride ? m->index.stride : (u16 ? 6 : 12);
+			pl.idx_src = (const char *)m->index.data;
+			pl.idx_on_device = is_device_ptr(m->index.data);
+			if (pl.idx_on_device && !pl.pos_on_device) { rtk_set_error("rtk_dev_scene_build: mesh %zu has device indices but host positions", mi); return nullptr; }
+			if (!pl.idx_on_device) {
+				if (!pl.pos_on_device) {
+					// the position buffer's extent is only known through the largest index used
 					max_vertex = 0;
 					for (size_t i = 0; i < nt; i++) {
-						const char *p = (const char *)m->index.data + i * istride;
+						const char *p = pl.idx_src + i * pl.istride;
 						for (int c = 0; c < 3; c++) {
 							const uint64_t v = u16 ? ((const uint16_t *)p)[c] : ((const uint32_t *)p)[c];
 							if (v > max_vertex) max_vertex = v;
 						}
 					}
 				}
-				const size_t ibytes = (nt - 1) * istride + (u16 ? 6 : 12);
-				if (!d_idx.alloc(ibytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
-				BUILD_CHECK(upload_staged(d_idx.p, m->index.data, ibytes));
-				idx_ptr = d_idx.p;
+				pl.ibytes = (nt - 1) * pl.istride + (u16 ? 6 : 12);
 			}
 		}
-		if (pos_on_device) {
-			pos_ptr = (const char *)m->position.data;
-		} else {
-			const size_t pbytes = (size_t)max_vertex * pstride + (f64 ? 24 : 12);
-			if (!d_pos.alloc(pbytes)) { rtk_set_error("device build: out of device memory"); return nullptr; }
-			BUILD_CHECK(upload_staged(d_pos.p, m->position.data, pbytes));
-			pos_ptr = d_pos.p;
-		}
-		stage("upload");
-		const unsigned iblocks = (unsigned)((nt + 255) / 256);
-		if (idx_kind == 0) launch_ingest<0>(f64, iblocks, pos_ptr, pstride, idx_ptr, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
-		else if (idx_kind == 1) launch_ingest<1>(f64, iblocks, pos_ptr, pstride, idx_ptr, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
-		else launch_ingest<2>(f64, iblocks, pos_ptr, pstride, idx_ptr, istride, (uint32_t)nt, base, in_pos.p, in_vidx.p);
-		BUILD_CHECK(hipGetLastError());
-		BUILD_CHECK(hipDeviceSynchronize());   // d_pos/d_idx are released at scope end
+		if (!pl.pos_on_device) pl.pbytes = (size_t)max_vertex * pl.pstride + (pl.f64 ? 24 : 12);
+		upload_bytes += padded(pl.pbytes) + padded(pl.ibytes);
 	}
-	if (n < 2) return build_tiny(desc, mesh_base, tiny_pos, tiny_vidx);
+
+	if (n < 2) {
+		std::vector<float> tiny_pos;
+		std::vector<uint32_t> tiny_vidx;
+		for (size_t mi = 0; mi < desc->num_meshes; mi++) {
+			const rtk_mesh *m = &desc->meshes[mi];
+			if (m->num_triangles == 0) continue;
+			tiny_pos.resize(9 * m->num_triangles);
+			tiny_vidx.resize(3 * m->num_triangles);
+			decode_mesh_on_host(m, tiny_pos.data(), tiny_vidx.data());
+		}
+		return build_tiny(desc, mesh_base, tiny_pos, tiny_vidx);
+	}
+
+	// ---- workspace -----------------------------------------------------------------------
+	// 63-bit Morton keys resolve 2^-21 of the scene per axis; for < 2^24 triangles the low 15 bits never
+	// decide a split that matters (lab: identical visit counts down to 30 bits at 1M triangles), so only
+	// the top 48 bits are kept and sorted: 6 radix passes instead of 8.
+	const uint32_t key_bits = n < (1u << 24) ? 48u : 63u;
+	const size_t sort_words = rtk_sort_scratch_words(n);
+	const size_t collapse_blocks = ((size_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK;
+	size_t need = upload_bytes + 64 * 256;
+	need += padded(9 * (size_t)n * 4) + padded(3 * (size_t)n * 4);                  // in_pos, in_vidx
+	need += 2 * padded((size_t)n * 8) + 2 * padded((size_t)n * 4);                  // keys a/b, vals a/b
+	need += padded(sort_words * 4) + padded(64) + padded(mesh_base.size() * 8);     // sort scratch, bounds, mesh_base
+	need += 2 * padded((size_t)n * 8) + 4 * padded((size_t)n * 4);                  // lr, range, parent_inner, parent_leaf, cont, arrive
+	need += padded((size_t)n * sizeof(BinNode));                                    // bin
+	need += 2 * padded((size_t)n * 4) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState));
+	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case)
+	Workspace &ws = g_workspace[device];
+	std::lock_guard<std::mutex> ws_lock(ws.mutex);
+	if (ws.cap < need) {
+		if (ws.base) (void)hipFree(ws.base);
+		ws.base = nullptr;
+		ws.cap = 0;
+		const size_t want = need + need / 8;
+		if (hipMalloc(&ws.base, want) != hipSuccess) {
+			(void)hipGetLastError();
+			if (hipMalloc(&ws.base, need) != hipSuccess) { ws.base = nullptr; rtk_set_error("device build: out of device memory (%zu bytes of workspace)", need); return nullptr; }
+			ws.cap = need;
+		} else ws.cap = want;
+	}
+	Arena ar = { ws.base, ws.cap, 0 };
+	stage("workspace");
+
+	// ---- 1 ingest ------------------------------------------------------------------
+	float *in_pos = ar.take<float>(9 * (size_t)n);
+	uint32_t *in_vidx = ar.take<uint32_t>(3 * (size_t)n);
+	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
+		const rtk_mesh *m = &desc->meshes[mi];
+		const MeshPlan &pl = plans[mi];
+		const size_t nt = m->num_triangles;
+		if (nt == 0) continue;
+		const uint32_t base = (uint32_t)mesh_base[mi];
+		if (pl.on_host_decode) {
+			std::vector<float> pos9(9 * nt);
+			std::vector<uint32_t> vidx3(3 * nt);
+			decode_mesh_on_host(m, pos9.data(), vidx3.data());
+			BUILD_CHECK(hipMemcpy(in_pos + 9 * (size_t)base, pos9.data(), pos9.size() * 4, hipMemcpyHostToDevice));
+			BUILD_CHECK(hipMemcpy(in_vidx + 3 * (size_t)base, vidx3.data(), vidx3.size() * 4, hipMemcpyHostToDevice));
+			continue;
+		}
+		// raw buffers go to the device as they are; the decode runs there
+		const char *idx_ptr = pl.idx_src, *pos_ptr = pl.pos_src;
+		if (pl.ibytes) {
+			char *d = ar.take<char>(pl.ibytes);
+			BUILD_CHECK(upload_staged(d, pl.idx_src, pl.ibytes));
+			idx_ptr = d;
+		}
+		if (pl.pbytes) {
+			char *d = ar.take<char>(pl.pbytes);
+			BUILD_CHECK(upload_staged(d, pl.pos_src, pl.pbytes));
+			pos_ptr = d;
+		}
+		const unsigned iblocks = (unsigned)((nt + 255) / 256);
+		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_pos, in_vidx);
+		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_pos, in_vidx);
+		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_pos, in_vidx);
+		BUILD_CHECK(hipGetLastError());
+	}
 	stage("ingest");
 
 	BuildParams bp;
@@ -882,118 +1135,118 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	if (bp.max_leaf > 63) bp.max_leaf = 63;     // 6-bit count in the blob's leaf header (rtk.c:188)
 
 	// ---- 2 bounds, 3 morton -----------------------------------------------------------
-	DevBuf<uint32_t> d_bounds;
-	DevBuf<unsigned long long> keys_a, keys_b;
-	DevBuf<uint32_t> vals_a, vals_b;
-	if (!d_bounds.alloc(6) || !keys_a.alloc(n) || !keys_b.alloc(n) || !vals_a.alloc(n) || !vals_b.alloc(n)) { rtk_set_error("device build: out of device memory"); return nullptr; }
+	uint32_t *d_bounds = ar.take<uint32_t>(16);
+	unsigned long long *keys_a = ar.take<unsigned long long>(n), *keys_b = ar.take<unsigned long long>(n);
+	uint32_t *vals_a = ar.take<uint32_t>(n), *vals_b = ar.take<uint32_t>(n);
+	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
+	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());
 	{
-		const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-		BUILD_CHECK(hipMemcpy(d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice));
-		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + SORT_BLOCK - 1) / SORT_BLOCK, (size_t)prop.multiProcessorCount * 8);
-		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(SORT_BLOCK), 0, 0, in_pos.p, n, d_bounds.p);
-		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos.p, n, d_bounds.p, keys_a.p, vals_a.p);
+		static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+		BUILD_CHECK(hipMemcpy(d_bounds, init, sizeof(init), hipMemcpyHostToDevice));
+		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + SORT_BLOCK - 1) / SORT_BLOCK, (size_t)num_cus * 8);
+		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(SORT_BLOCK), 0, 0, in_pos, n, d_bounds);
+		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos, n, d_bounds, keys_a, vals_a, 63u - key_bits);
 		BUILD_CHECK(hipGetLastError());
 	}
-
 	stage("morton");
-	// ---- 4 sort ------------------------------------------------------------------------
-	{
-		const uint32_t num_units = (n + SORT_TILE - 1u) / SORT_TILE;
-		const unsigned blocks = num_units;
-		DevBuf<uint32_t> hist;
-		if (!hist.alloc(256 * (size_t)num_units)) { rtk_set_error("device build: out of device memory"); return nullptr; }
-		unsigned long long *kin = keys_a.p, *kout = keys_b.p;
-		uint32_t *vin = vals_a.p, *vout = vals_b.p;
-		for (uint32_t shift = 0; shift < 64; shift += 8) {   // 63 key bits -> 8 passes; an even count leaves the result in *_a
-			hipLaunchKernelGGL(k_sort_hist, dim3(blocks), dim3(SORT_BLOCK), 0, 0, kin, n, shift, num_units, hist.p);
-			if (!exclusive_scan_u32(hist.p, 256 * (size_t)num_units)) { rtk_set_error("device build: scan failed: %s", hipGetErrorString(hipGetLastError())); return nullptr; }
-			hipLaunchKernelGGL(k_sort_scatter, dim3(blocks), dim3(SORT_BLOCK), 0, 0, kin, vin, n, shift, num_units, hist.p, kout, vout);
-			BUILD_CHECK(hipGetLastError());
-			std::swap(kin, kout);
-			std::swap(vin, vout);
-		}
-		BUILD_CHECK(hipDeviceSynchronize());
-	}
 
+	// ---- 4 sort: no allocation, no host synchronisation ------------------------------------
+	const bool in_b = rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, 0);
+	const unsigned long long *keys = in_b ? keys_b : keys_a;
+	const uint32_t *vals = in_b ? vals_b : vals_a;
+	BUILD_CHECK(hipGetLastError());
 	stage("sort");
+
 	// ---- 5 emit: final triangle records in Morton order ----------------------------------
 	rtk_dev_scene *ds = new rtk_dev_scene();
 	ds->device = device;
-	ds->num_cus = prop.multiProcessorCount;
+	ds->num_cus = num_cus;
 	ds->mesh_base = mesh_base;
 	auto fail = [&](const char *what) -> rtk_dev_scene * {
 		rtk_set_error("device build: %s: %s", what, hipGetErrorString(hipGetLastError()));
 		rtk_dev_scene_free(ds);
 		return nullptr;
 	};
-	auto dev_alloc = [&](size_t bytes) -> void * {
+	auto dev_alloc = [&](size_t bytes) -> char * {
 		void *p = nullptr;
 		if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
 		ds->allocs.push_back(p);
 		ds->total_bytes += bytes;
-		return p;
+		return (char *)p;
 	};
-	DevTri *d_tris = (DevTri *)dev_alloc((size_t)n * sizeof(DevTri));
-	uint32_t *d_vertex_index = (uint32_t *)dev_alloc(3 * (size_t)n * 4);
-	uint32_t *d_prim_slot = (uint32_t *)dev_alloc((size_t)n * 4);
-	uint32_t *d_slot_mesh = (uint32_t *)dev_alloc((size_t)n * 4);
-	uint32_t *d_slot_tri = (uint32_t *)dev_alloc((size_t)n * 4);
-	DevBuf<unsigned long long> d_mesh_base;
-	if (!d_tris || !d_vertex_index || !d_prim_slot || !d_slot_mesh || !d_slot_tri || !d_mesh_base.alloc(mesh_base.size())) return fail("out of device memory");
+	// one allocation for the triangle records and their side arrays
+	const size_t o_vidx = padded((size_t)n * sizeof(DevTri)), o_pslot = o_vidx + padded(3 * (size_t)n * 4), o_smesh = o_pslot + padded((size_t)n * 4),
+		o_stri = o_smesh + padded((size_t)n * 4), tri_block = o_stri + padded((size_t)n * 4);
+	char *tri_mem = dev_alloc(tri_block);
+	if (!tri_mem) return fail("out of device memory");
+	DevTri *d_tris = (DevTri *)tri_mem;
+	uint32_t *d_vertex_index = (uint32_t *)(tri_mem + o_vidx);
+	uint32_t *d_prim_slot = (uint32_t *)(tri_mem + o_pslot);
+	uint32_t *d_slot_mesh = (uint32_t *)(tri_mem + o_smesh);
+	uint32_t *d_slot_tri = (uint32_t *)(tri_mem + o_stri);
 	{
 		std::vector<unsigned long long> mb(mesh_base.begin(), mesh_base.end());
-		if (hipMemcpy(d_mesh_base.p, mb.data(), mb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
-		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos.p, in_vidx.p, vals_a.p, n, d_mesh_base.p,
+		if (hipMemcpy(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos, in_vidx, vals, n, d_mesh_base,
 			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
 	}
-
 	stage("emit");
+
 	// ---- 6 karras, 7 refit ------------------------------------------------------------------
-	DevBuf<int> d_left, d_right, d_parent_inner, d_parent_leaf;
-	DevBuf<uint32_t> d_first, d_last, d_arrive;
-	DevBuf<BinNode> d_bin;
-	if (!d_left.alloc(n) || !d_right.alloc(n) || !d_parent_inner.alloc(n) || !d_parent_leaf.alloc(n) || !d_first.alloc(n) ||
-		!d_last.alloc(n) || !d_arrive.alloc(n) || !d_bin.alloc(n)) return fail("out of device memory");
-	if (hipMemset(d_arrive.p, 0, (size_t)n * 4) != hipSuccess) return fail("memset");
-	hipLaunchKernelGGL(k_karras, dim3((n + 255u) / 256u), dim3(256), 0, 0, keys_a.p, (int)n, d_left.p, d_right.p, d_parent_inner.p,
-		d_parent_leaf.p, d_first.p, d_last.p);
-	hipLaunchKernelGGL(k_refit, dim3((n + 255u) / 256u), dim3(256), 0, 0, d_tris, (int)n, d_left.p, d_right.p, d_parent_inner.p,
-		d_parent_leaf.p, d_arrive.p, d_bin.p, bp);
-	if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("karras/refit");
+	int2 *d_lr = ar.take<int2>(n);
+	uint2 *d_range = ar.take<uint2>(n);
+	int *d_parent_inner = ar.take<int>(n), *d_parent_leaf = ar.take<int>(n), *d_cont = ar.take<int>(n);
+	uint32_t *d_arrive = ar.take<uint32_t>(n);
+	BinNode *d_bin = ar.take<BinNode>(n);
+	if (hipMemsetAsync(d_arrive, 0, (size_t)n * 4, 0) != hipSuccess) return fail("memset");
+	hipLaunchKernelGGL(k_karras, dim3((n + 255u) / 256u), dim3(256), 0, 0, keys, (int)n, d_lr, d_range, d_parent_inner, d_parent_leaf);
+	stage("karras");
+	hipLaunchKernelGGL(k_refit_tile, dim3((n + REFIT_TILE - 1u) / REFIT_TILE), dim3(REFIT_BLOCK), 0, 0, d_tris, (int)n, d_lr, d_range,
+		d_parent_inner, d_parent_leaf, d_bin, d_cont, bp);
+	hipLaunchKernelGGL(k_refit_top, dim3((n + 255u) / 256u), dim3(256), 0, 0, d_tris, (int)n, d_lr, d_parent_inner, d_cont, d_arrive, d_bin, bp);
+	if (hipGetLastError() != hipSuccess) return fail("karras/refit");
+	stage("refit");
 
-	stage("tree+refit");
-	// ---- 8 collapse, one launch per level of the 4-wide tree -----------------------------------
-	DevBuf<DevNode> d_nodes_tmp;       // worst case one wide node per binary inner node
-	DevBuf<WideJob> jobs_a, jobs_b;
-	DevBuf<uint32_t> d_next;
-	if (!d_nodes_tmp.alloc(n) || !jobs_a.alloc(n) || !jobs_b.alloc(n) || !d_next.alloc(1)) return fail("out of device memory");
-	uint32_t total_nodes = 1, level_count = 1, depth = 0;
+	// ---- 8 collapse, three launches per level of the 4-wide tree, sizes stay on the device ----------
+	int *jobs_a = ar.take<int>(n), *jobs_b = ar.take<int>(n);
+	int4 *d_dec = ar.take<int4>(n);
+	uint32_t *d_info = ar.take<uint32_t>(n);
+	uint32_t *d_block_sums = ar.take<uint32_t>(collapse_blocks);
+	LevelState *d_state = ar.take<LevelState>(1);
+	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
+	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
+	LevelState h_state = {};
 	{
-		const WideJob rootjob = { 0, 0u };
-		if (hipMemcpy(jobs_a.p, &rootjob, sizeof(rootjob), hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
+		h_state.count[0] = 1;
+		const int root_job = 0;
+		if (hipMemcpy(d_state, &h_state, sizeof(h_state), hipMemcpyHostToDevice) != hipSuccess ||
+			hipMemcpy(jobs_a, &root_job, sizeof(root_job), hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
 	}
-	WideJob *jin = jobs_a.p, *jout = jobs_b.p;
-	while (level_count) {
-		depth++;
-		if (hipMemset(d_next.p, 0, 4) != hipSuccess) return fail("memset");
-		hipLaunchKernelGGL(k_collapse_level, dim3((level_count + 127u) / 128u), dim3(128), 0, 0, jin, level_count, d_left.p, d_right.p,
-			d_first.p, d_last.p, d_bin.p, d_tris, d_nodes_tmp.p, jout, d_next.p, total_nodes);
-		uint32_t next = 0;
-		if (hipGetLastError() != hipSuccess || hipMemcpy(&next, d_next.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse level");
-		total_nodes += next;
-		level_count = next;
-		std::swap(jin, jout);
-		if (depth > 4096) return fail("collapse did not terminate");
+	uint32_t level = 0;
+	for (;;) {
+		for (int k = 0; k < 8; k++, level++) {
+			// a level of the 4-wide tree has at most 4^level nodes, and never more than there are binary nodes
+			const uint64_t bound = level >= 15 ? (uint64_t)n : std::min<uint64_t>((uint64_t)1 << (2 * level), n);
+			const unsigned blocks = (unsigned)std::min<uint64_t>((bound + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
+			int *jin = (level & 1u) ? jobs_b : jobs_a, *jout = (level & 1u) ? jobs_a : jobs_b;
+			hipLaunchKernelGGL(k_collapse_decide, dim3(blocks), dim3(COLLAPSE_BLOCK), 0, 0, jin, d_state, level, d_lr, d_bin, d_dec, d_info, d_block_sums);
+			hipLaunchKernelGGL(k_collapse_scan, dim3(1), dim3(1024), 0, 0, d_block_sums, d_state, level);
+			hipLaunchKernelGGL(k_collapse_emit, dim3(blocks), dim3(COLLAPSE_BLOCK), 0, 0, jin, d_state, level, d_range, d_bin, d_dec, d_info,
+				d_block_sums, d_tris, d_nodes_tmp, jout);
+		}
+		if (hipGetLastError() != hipSuccess || hipMemcpy(&h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse");
+		if (h_state.count[level & 1u] == 0) break;
+		if (level > 8192) return fail("collapse did not terminate");
 	}
-
+	const uint32_t total_nodes = h_state.total_nodes, depth = h_state.depth;
 	stage("collapse");
-	// shrink the node array to what was used
+
+	// the node array at its final size
 	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
 	if (!d_nodes) return fail("out of device memory");
-	if (hipMemcpy(d_nodes, d_nodes_tmp.p, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice) != hipSuccess) return fail("copy");
-	if (hipMalloc(&ds->d_counter, RTK_COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess) return fail("out of device memory");
-	if (hipDeviceSynchronize() != hipSuccess) return fail("sync");
+	if (hipMemcpyAsync(d_nodes, d_nodes_tmp, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail("copy");
+	if (hipStreamSynchronize(0) != hipSuccess) return fail("sync");   // the workspace is handed back below
 
 	ds->view.nodes = d_nodes;
 	ds->view.tris = d_tris;
@@ -1008,6 +1261,11 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	ds->stack_entries = 3u * depth + 1u;
 	stage("finish");
 	ds->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+	if (getenv("RTK_AMD_KEEP_WORKSPACE") && atoi(getenv("RTK_AMD_KEEP_WORKSPACE")) == 0) {
+		(void)hipFree(ws.base);
+		ws.base = nullptr;
+		ws.cap = 0;
+	}
 	return ds;
 }
 

@@ -45,7 +45,15 @@ extern "C" int rtk_amd_set_device(int device)
 extern "C" rtk_dev_scene *rtk_dev_scene_upload(const rtk_scene *scene)
 {
 	HostBvh h;
-	if (rtk_blob_to_host_bvh(scene, &h) != RTK_AMD_OK) return nullptr;
+	if (rtk_blob_to_host_bvh(scene, scene ? (size_t)scene->size_in_bytes : 0, &h) != RTK_AMD_OK) return nullptr;
+	return rtk_dev_scene_from_host_bvh(h);
+}
+
+extern "C" rtk_dev_scene *rtk_dev_scene_upload_buffer(const void *blob, size_t blob_bytes)
+{
+	HostBvh h;
+	if (!blob || blob_bytes < sizeof(rtk_scene)) { rtk_set_error("scene blob: buffer smaller than the header"); return nullptr; }
+	if (rtk_blob_to_host_bvh(static_cast<const rtk_scene *>(blob), blob_bytes, &h) != RTK_AMD_OK) return nullptr;
 	return rtk_dev_scene_from_host_bvh(h);
 }
 
@@ -56,9 +64,7 @@ extern "C" void rtk_dev_scene_free(rtk_dev_scene *ds)
 	if (!ds) return;
 	rtk_export_forget(ds);
 	for (void *p : ds->allocs) (void)hipFree(p);
-	if (ds->d_counter) (void)hipFree(ds->d_counter);
-	if (ds->d_spill) (void)hipFree(ds->d_spill);
-	if (ds->d_sort) (void)hipFree(ds->d_sort);
+	for (LaunchScratch *s : ds->scratch) rtk_scratch_free(s);
 	delete ds;
 }
 
@@ -110,6 +116,18 @@ extern "C" int rtk_dev_trace_rays_any(const rtk_dev_scene *ds, const rtk_ray *d_
 	return rtk_launch_trace(ds, d_rays, n, nullptr, d_occluded, opts, (hipStream_t)stream, true, nullptr);
 }
 
+extern "C" int rtk_dev_trace_rays_filtered(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	rtk_hit_record *d_hits, const rtk_dev_filter *filter, const rtk_trace_opts *opts, void *stream)
+{
+	return rtk_launch_trace(ds, d_rays, n, d_hits, nullptr, opts, (hipStream_t)stream, false, nullptr, filter);
+}
+
+extern "C" int rtk_dev_trace_rays_any_filtered(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	uint8_t *d_occluded, const rtk_dev_filter *filter, const rtk_trace_opts *opts, void *stream)
+{
+	return rtk_launch_trace(ds, d_rays, n, nullptr, d_occluded, opts, (hipStream_t)stream, true, nullptr, filter);
+}
+
 extern "C" int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_trace_counters *out)
 {
@@ -124,6 +142,11 @@ extern "C" int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk
 	return rtk_launch_trace(ds, d_rays, n, nullptr, d_occluded, opts, nullptr, true, out);
 }
 
+extern "C" int rtk_dev_trace_status(const rtk_dev_scene *ds, void *stream)
+{
+	return rtk_trace_status(ds, (hipStream_t)stream);
+}
+
 extern "C" int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n,
 	rtk_hit *d_hits, uint8_t *d_mask, void *stream)
 {
@@ -131,26 +154,62 @@ extern "C" int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record
 }
 
 // ---------------------------------------------------------------------------- residency cache
+//
+// Host-pointer calls (rtk_trace_ray[s], the reference's own signatures) find the device copy of a blob
+// through its address. The address alone is not an identity: rtk_finish_build_to writes into caller
+// memory that the caller releases with free(), so a different blob can later live at the same address.
+// Every entry therefore carries a fingerprint of the blob (size, header, root node and samples across
+// the body) that is re-checked on every lookup; a mismatch drops the device copy and uploads again.
 
-static std::mutex g_cache_mutex;
-static std::unordered_map<const rtk_scene *, rtk_dev_scene *> g_cache;
+namespace {
 
-static rtk_dev_scene *resident(const rtk_scene *scene)
+uint64_t fnv1a(const void *data, size_t n, uint64_t h)
 {
+	const unsigned char *p = static_cast<const unsigned char *>(data);
+	for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+	return h;
+}
+
+uint64_t blob_fingerprint(const rtk_scene *scene)
+{
+	const char *b = reinterpret_cast<const char *>(scene);
+	const uint64_t size = scene->size_in_bytes;
+	uint64_t h = fnv1a(scene, sizeof(rtk_scene), 0xcbf29ce484222325ull);
+	if (size < 256 || size > ((uint64_t)1 << 48)) return h;        // not a plausible blob; the loader will refuse it
+	h = fnv1a(b + 128, 128, h);                                       // root node
+	const uint64_t step = size / 61 + 1;
+	for (uint64_t at = 256; at + 64 <= size; at += step) h = fnv1a(b + at, 64, h);
+	return fnv1a(b + size - 64, 64, h);
+}
+
+struct CacheEntry { rtk_dev_scene *ds; uint64_t fingerprint; };
+std::mutex g_cache_mutex;
+std::unordered_map<const rtk_scene *, CacheEntry> g_cache;
+
+rtk_dev_scene *resident(const rtk_scene *scene)
+{
+	const uint64_t fp = blob_fingerprint(scene);
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
 	auto it = g_cache.find(scene);
-	if (it != g_cache.end()) return it->second;
+	if (it != g_cache.end()) {
+		if (it->second.fingerprint == fp) return it->second.ds;
+		rtk_dev_scene_free(it->second.ds);                            // another blob lives at this address now
+		g_cache.erase(it);
+	}
 	rtk_dev_scene *ds = rtk_dev_scene_upload(scene);
-	if (ds) g_cache[scene] = ds;
+	if (ds) g_cache[scene] = CacheEntry{ ds, fp };
 	return ds;
 }
 
+} // namespace
+
 void rtk_cache_adopt(const rtk_scene *scene, rtk_dev_scene *ds)
 {
+	const uint64_t fp = blob_fingerprint(scene);
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
 	auto it = g_cache.find(scene);
-	if (it != g_cache.end()) rtk_dev_scene_free(it->second);
-	g_cache[scene] = ds;
+	if (it != g_cache.end()) rtk_dev_scene_free(it->second.ds);
+	g_cache[scene] = CacheEntry{ ds, fp };
 }
 
 extern "C" void rtk_amd_forget_scene(const rtk_scene *scene)
@@ -158,9 +217,113 @@ extern "C" void rtk_amd_forget_scene(const rtk_scene *scene)
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
 	auto it = g_cache.find(scene);
 	if (it == g_cache.end()) return;
-	rtk_dev_scene_free(it->second);
+	rtk_dev_scene_free(it->second.ds);
 	g_cache.erase(it);
 }
+
+// ---------------------------------------------------------------------------- host-pointer tracing
+//
+// Each host thread owns a stream, pinned staging memory and device buffers for one chunk of rays, all
+// created on first use and kept: a call allocates nothing in steady state (the first version paid four
+// hipMalloc + four hipFree per rtk_trace_ray). Batches larger than a chunk stream through in pieces.
+
+namespace {
+
+const size_t HOST_CHUNK = (size_t)1 << 18;     // rays per piece: 8 MB of rays, 17 MB of full hits
+
+struct HostCtx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	size_t cap = 0;                            // rays
+	char *pinned = nullptr;                    // [rays | records | hits | mask | after]
+	char *dev = nullptr;
+	rtk_ray *h_rays = nullptr, *d_rays = nullptr;
+	rtk_hit_record *h_rec = nullptr, *d_rec = nullptr;
+	rtk_hit *h_hits = nullptr, *d_hits = nullptr;
+	uint8_t *h_mask = nullptr, *d_mask = nullptr;
+	rtk_hit_record *h_after = nullptr, *d_after = nullptr;
+
+	void release()
+	{
+		if (pinned) (void)hipHostFree(pinned);
+		if (dev) (void)hipFree(dev);
+		pinned = dev = nullptr;
+		cap = 0;
+	}
+	~HostCtx()
+	{
+		release();
+		if (stream) (void)hipStreamDestroy(stream);
+	}
+	bool ensure(size_t n)
+	{
+		int cur = 0;
+		if (hipGetDevice(&cur) != hipSuccess) { rtk_set_error("no usable HIP device: %s", hipGetErrorString(hipGetLastError())); return false; }
+		if (cur != device) {                   // the thread moved to another GPU
+			release();
+			if (stream) (void)hipStreamDestroy(stream);
+			stream = nullptr;
+			device = cur;
+		}
+		if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+			rtk_set_error("hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError()));
+			stream = nullptr;
+			return false;
+		}
+		if (n <= cap) return true;
+		release();
+		size_t want = 64;
+		while (want < n) want <<= 1;
+		const size_t per_ray = sizeof(rtk_ray) + 2 * sizeof(rtk_hit_record) + sizeof(rtk_hit) + 4 /* mask, kept 4-aligned */;
+		if (hipHostMalloc((void **)&pinned, want * per_ray, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&dev, want * per_ray) != hipSuccess) {
+			rtk_set_error("rtk_trace_rays: staging allocation failed (%zu rays): %s", want, hipGetErrorString(hipGetLastError()));
+			release();
+			return false;
+		}
+		cap = want;
+		auto carve = [&](char *base) {
+			size_t off = 0;
+			auto take = [&](size_t bytes) { char *p = base + off; off += bytes; return p; };
+			rtk_ray *r = (rtk_ray *)take(want * sizeof(rtk_ray));
+			rtk_hit_record *rec = (rtk_hit_record *)take(want * sizeof(rtk_hit_record));
+			rtk_hit_record *aft = (rtk_hit_record *)take(want * sizeof(rtk_hit_record));
+			rtk_hit *hh = (rtk_hit *)take(want * sizeof(rtk_hit));
+			uint8_t *m = (uint8_t *)take(want * 4);
+			if (base == pinned) { h_rays = r; h_rec = rec; h_after = aft; h_hits = hh; h_mask = m; }
+			else { d_rays = r; d_rec = rec; d_after = aft; d_hits = hh; d_mask = m; }
+		};
+		carve(pinned);
+		carve(dev);
+		return true;
+	}
+};
+
+thread_local HostCtx t_ctx;
+
+// One piece (n <= chunk capacity): rays up, trace (optionally restricted to candidates after h_after), expand,
+// hits and mask down. Returns false with the error set.
+bool trace_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n, bool want_hits, bool with_after)
+{
+	memcpy(c.h_rays, rays, n * sizeof(rtk_ray));
+	if (hipMemcpyAsync(c.d_rays, c.h_rays, n * sizeof(rtk_ray), hipMemcpyHostToDevice, c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays: H2D copy failed"); return false; }
+	rtk_dev_filter f;
+	memset(&f, 0, sizeof(f));
+	f.struct_size = sizeof(f);
+	if (with_after) {
+		if (hipMemcpyAsync(c.d_after, c.h_after, n * sizeof(rtk_hit_record), hipMemcpyHostToDevice, c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays: H2D copy failed"); return false; }
+		f.d_after = c.d_after;
+	}
+	if (rtk_launch_trace(ds, c.d_rays, n, c.d_rec, nullptr, nullptr, c.stream, false, nullptr, with_after ? &f : nullptr) != RTK_AMD_OK) return false;
+	if (rtk_launch_expand(ds, c.d_rec, n, want_hits ? c.d_hits : nullptr, c.d_mask, c.stream) != RTK_AMD_OK) return false;
+	bool ok = hipMemcpyAsync(c.h_mask, c.d_mask, n, hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+	ok = ok && hipMemcpyAsync(c.h_rec, c.d_rec, n * sizeof(rtk_hit_record), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+	if (want_hits) ok = ok && hipMemcpyAsync(c.h_hits, c.d_hits, n * sizeof(rtk_hit), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+	if (!ok) { rtk_set_error("rtk_trace_rays: D2H copy failed: %s", hipGetErrorString(hipGetLastError())); return false; }
+	if (rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return false;      // synchronises the stream
+	return true;
+}
+
+} // namespace
 
 extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask)
 {
@@ -168,71 +331,110 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 	if (n == 0) return 0;
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
+	HostCtx &c = t_ctx;
+	if (!c.ensure(n < HOST_CHUNK ? n : HOST_CHUNK)) return (size_t)-1;
+	size_t count = 0;
+	for (size_t at = 0; at < n; at += HOST_CHUNK) {
+		const size_t m = n - at < HOST_CHUNK ? n - at : HOST_CHUNK;
+		if (!trace_piece(ds, c, rays + at, m, hits != nullptr, false)) return (size_t)-1;
+		for (size_t i = 0; i < m; i++) {
+			if (c.h_mask[i]) { count++; if (hits) hits[at + i] = c.h_hits[i]; }   // misses stay untouched (rtk.c:571-576)
+			if (hit_mask) hit_mask[at + i] = c.h_mask[i];
+		}
+	}
+	return count;
+}
 
-	rtk_ray *d_rays = nullptr;
-	rtk_hit_record *d_rec = nullptr;
-	rtk_hit *d_hits = nullptr;
-	uint8_t *d_mask = nullptr;
-	size_t result = (size_t)-1;
-	std::vector<rtk_hit> h_hits;
-	std::vector<uint8_t> h_mask(n);
-	do {
-		if (hipMalloc(&d_rays, n * sizeof(rtk_ray)) != hipSuccess || hipMalloc(&d_rec, n * sizeof(rtk_hit_record)) != hipSuccess ||
-			hipMalloc(&d_mask, n) != hipSuccess || (hits && hipMalloc(&d_hits, n * sizeof(rtk_hit)) != hipSuccess)) {
-			rtk_set_error("rtk_trace_rays: device allocation failed"); break;
+// Batch form of rtk_trace_ray_filter (rtk.h:117, 130; a stub in the reference, rtk.c:579-582). Semantics:
+// for every ray the closest candidate hit the filter accepts. Candidates of a ray are offered in increasing
+// (t, primitive id) order -- every candidate, including several at one and the same t -- until one is
+// accepted or none is left. The callback runs on the host, so the batch goes in rounds: trace all undecided
+// rays, ask the filter about each one's candidate, and trace the rejected ones again restricted to what
+// comes after the rejected candidate. The number of launches is the longest rejection chain of any ray,
+// not the number of candidates.
+extern "C" size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask,
+	rtk_filter_fn *filter, void *filter_user)
+{
+	if (!filter) return rtk_trace_rays(scene, rays, n, hits, hit_mask);
+	if (!scene || (!rays && n)) { rtk_set_error("rtk_trace_rays_filter: NULL argument"); return (size_t)-1; }
+	if (n == 0) return 0;
+	rtk_dev_scene *ds = resident(scene);
+	if (!ds) return (size_t)-1;
+	HostCtx &c = t_ctx;
+	if (!c.ensure(n < HOST_CHUNK ? n : HOST_CHUNK)) return (size_t)-1;
+	size_t count = 0;
+	std::vector<size_t> todo, next;
+	std::vector<rtk_ray> piece_rays;
+	std::vector<rtk_hit_record> after, next_after;
+	for (size_t at = 0; at < n; at += HOST_CHUNK) {
+		const size_t m = n - at < HOST_CHUNK ? n - at : HOST_CHUNK;
+		todo.resize(m);
+		for (size_t i = 0; i < m; i++) todo[i] = at + i;
+		after.assign(m, rtk_hit_record{ 0.0f, 0.0f, 0.0f, RTK_PRIM_NONE });
+		if (hit_mask) memset(hit_mask + at, 0, m);
+		for (unsigned round = 0; !todo.empty(); round++) {
+			if (round > (1u << 16)) { rtk_set_error("rtk_trace_rays_filter: a ray had more than 65536 rejected candidates"); return (size_t)-1; }
+			piece_rays.resize(todo.size());
+			for (size_t k = 0; k < todo.size(); k++) { piece_rays[k] = rays[todo[k]]; c.h_after[k] = after[k]; }
+			if (!trace_piece(ds, c, piece_rays.data(), todo.size(), true, round > 0)) return (size_t)-1;
+			next.clear();
+			next_after.clear();
+			for (size_t k = 0; k < todo.size(); k++) {
+				if (!c.h_mask[k]) continue;                                   // no candidate left: a miss
+				const size_t i = todo[k];
+				if (filter(filter_user, &rays[i], &c.h_hits[k])) {
+					count++;
+					if (hits) hits[i] = c.h_hits[k];
+					if (hit_mask) hit_mask[i] = 1;
+				} else {
+					next.push_back(i);
+					next_after.push_back(c.h_rec[k]);                          // continue after this (t, prim)
+				}
+			}
+			todo.swap(next);
+			after.swap(next_after);
 		}
-		if (hipMemcpy(d_rays, rays, n * sizeof(rtk_ray), hipMemcpyHostToDevice) != hipSuccess) { rtk_set_error("rtk_trace_rays: H2D copy failed"); break; }
-		if (rtk_launch_trace(ds, d_rays, n, d_rec, nullptr, nullptr, nullptr, false, nullptr) != RTK_AMD_OK) break;
-		if (rtk_launch_expand(ds, d_rec, n, d_hits, d_mask, nullptr) != RTK_AMD_OK) break;
-		if (hipMemcpy(h_mask.data(), d_mask, n, hipMemcpyDeviceToHost) != hipSuccess) { rtk_set_error("rtk_trace_rays: D2H copy failed: %s", hipGetErrorString(hipGetLastError())); break; }
-		if (hits) {
-			h_hits.resize(n);
-			if (hipMemcpy(h_hits.data(), d_hits, n * sizeof(rtk_hit), hipMemcpyDeviceToHost) != hipSuccess) { rtk_set_error("rtk_trace_rays: D2H copy failed"); break; }
-		}
-		size_t count = 0;
-		for (size_t i = 0; i < n; i++) {
-			if (h_mask[i]) { count++; if (hits) hits[i] = h_hits[i]; }   // misses stay untouched (rtk.c:571-576)
-			if (hit_mask) hit_mask[i] = h_mask[i];
-		}
-		result = count;
-	} while (0);
-	if (d_rays) (void)hipFree(d_rays);
-	if (d_rec) (void)hipFree(d_rec);
-	if (d_hits) (void)hipFree(d_hits);
-	if (d_mask) (void)hipFree(d_mask);
-	return result;
+	}
+	return count;
 }
 
 // ---------------------------------------------------------------------------- rtk.h: trace
 
-// reference rtk.h:129 / rtk.c:543-577 -- a batch of one on the GPU. Correct and
-// re-entrant, but a launch per ray: throughput callers use rtk_trace_rays.
+// reference rtk.h:129 / rtk.c:543-577 -- a batch of one on the GPU: one small copy up, two launches, one
+// copy down on the calling thread's own stream, no allocation in steady state. Safe from any number of
+// threads on one scene. A GPU round trip per ray stays orders of magnitude slower than the batch calls;
+// throughput callers use rtk_trace_rays / rtk_dev_trace_rays.
 extern "C" bool rtk_trace_ray(const rtk_scene *scene, const rtk_ray *ray, rtk_hit *hit)
 {
 	uint8_t m = 0;
 	rtk_hit h;
-	if (!ray || !hit) return false;
+	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray: NULL argument"); return false; }
 	const size_t r = rtk_trace_rays(scene, ray, 1, &h, &m);
 	if (r == (size_t)-1) {
+		// The signature has no error channel and "miss" would be a wrong answer, not an error: report and stop,
+		// unless the host opted into soft failures (then: false, with rtk_amd_last_error() set).
+		if (getenv("RTK_AMD_SOFT_ERRORS")) return false;
 		fprintf(stderr, "rtk_trace_ray: %s\n", g_error);
-		abort();   // never answer "miss" because the GPU path is unavailable
+		abort();
 	}
 	if (m) *hit = h;
 	return m != 0;
 }
 
-// reference rtk.h:117,130 (stub at rtk.c:579-582). Semantics defined here: the closest
-// hit that the filter accepts. Candidates are offered in increasing t; a rejected
-// candidate moves the open interval past its t.
+// reference rtk.h:117,130 (stub at rtk.c:579-582): the closest hit that the filter accepts; see
+// rtk_trace_rays_filter for the order in which candidates are offered.
 extern "C" bool rtk_trace_ray_filter(const rtk_scene *scene, const rtk_ray *ray, rtk_hit *hit, rtk_filter_fn *filter, void *filter_user)
 {
+	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray_filter: NULL argument"); return false; }
 	if (!filter) return rtk_trace_ray(scene, ray, hit);
-	rtk_ray r = *ray;
-	for (int guard = 0; guard < (1 << 20); guard++) {
-		rtk_hit h;
-		if (!rtk_trace_ray(scene, &r, &h)) return false;
-		if (filter(filter_user, ray, &h)) { *hit = h; return true; }
-		r.min_t = h.t;
+	uint8_t m = 0;
+	rtk_hit h;
+	const size_t r = rtk_trace_rays_filter(scene, ray, 1, &h, &m, filter, filter_user);
+	if (r == (size_t)-1) {
+		if (getenv("RTK_AMD_SOFT_ERRORS")) return false;
+		fprintf(stderr, "rtk_trace_ray_filter: %s\n", g_error);
+		abort();
 	}
-	return false;
+	if (m) *hit = h;
+	return m != 0;
 }

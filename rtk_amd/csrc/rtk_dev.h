@@ -11,11 +11,13 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <vector>
 
 #include "rtk.h"
 #include "rtk_amd.h"
 
+#define RTK_MAX_DEVICES 64       // per-device tables (workspaces, cached properties)
 #define RTK_REF_NONE 0xffffffffu  // empty child slot / "no node"
 #define RTK_REF_LEAF 0x80000000u  // leaf: low 31 bits = first triangle slot
 #define RTK_TRI_LAST 1u           // DevTri.flags: last triangle of its leaf
@@ -23,6 +25,7 @@
 // heads, each on its own 128-byte line (one word serves only ~88 atomics/us on MI355X).
 #define RTK_QUEUES 8
 #define RTK_QUEUE_WORD(q) (16 + 16 * (q))
+#define RTK_ERROR_WORD 10          // non-zero: a traversal stack overflowed (cannot happen for a validated tree)
 #define RTK_COUNTER_WORDS (16 + 16 * RTK_QUEUES)
 
 struct DevNode {
@@ -54,6 +57,21 @@ struct DevSceneView {
 	uint32_t num_prims;
 };
 
+// Device memory a launch writes besides its outputs: work-queue heads and visit counters, the global
+// part of the traversal stacks, and the ray-reordering buffers. One set per (scene, stream): launches on
+// one stream are ordered by the stream, launches on different streams (or from different host threads)
+// never share a set, so tracing one scene from many threads is safe (the reference's rtk_trace_ray is a
+// pure function of a const scene, rtk.c:543-577).
+struct LaunchScratch {
+	hipStream_t stream = nullptr;
+	unsigned long long *d_counter = nullptr;   // RTK_COUNTER_WORDS
+	uint2 *d_spill = nullptr;
+	size_t spill_entries_per_lane = 0;
+	size_t spill_lanes = 0;
+	void *d_sort = nullptr;                     // ray reordering scratch (RTK_TRACE_SORT_RAYS), grown on demand
+	size_t sort_capacity = 0;                   // rays
+};
+
 struct rtk_dev_scene {
 	int device = 0;
 	DevSceneView view = {};
@@ -65,14 +83,9 @@ struct rtk_dev_scene {
 	double build_ms = 0.0;
 	// owned device allocations
 	std::vector<void *> allocs;
-	// per-scene scratch for launches (lazily sized)
-	unsigned long long *d_counter = nullptr;   // ray pool head + visit counters (8 x u64)
-	uint2 *d_spill = nullptr;
-	// ray reordering scratch (RTK_TRACE_SORT_RAYS), grown on demand
-	void *d_sort = nullptr;
-	size_t sort_capacity = 0;                   // rays
-	size_t spill_entries_per_lane = 0;
-	size_t spill_lanes = 0;
+	// per-stream launch scratch, created on first use; the mutex covers the list and the enqueue of a launch
+	std::mutex scratch_mutex;
+	std::vector<LaunchScratch *> scratch;
 	int num_cus = 0;
 };
 
@@ -96,7 +109,7 @@ struct HostBvh {
 	std::vector<uint64_t> mesh_base;
 	uint32_t max_depth = 0;
 };
-int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out);
+int rtk_blob_to_host_bvh(const rtk_scene *scene, size_t avail, HostBvh *out);
 rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
 
 // -- radix sort shared with the builder (rtk_build.hip) --
@@ -106,6 +119,9 @@ bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b
 
 // -- trace launches (rtk_trace.hip) --
 int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
-	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted);
+	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
+	const rtk_dev_filter *filter = nullptr);
+int rtk_trace_status(const rtk_dev_scene *ds, hipStream_t stream);
+void rtk_scratch_free(LaunchScratch *s);
 int rtk_launch_expand(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,
 	uint8_t *d_mask, hipStream_t stream);

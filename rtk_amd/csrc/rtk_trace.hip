@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 __device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
 
@@ -66,7 +68,19 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 	ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
-template <int MODE /*0 closest, 1 any*/, bool COUNT>
+// A push that does not fit the stack (LDS entries + the global spill area sized from the tree depth) is
+// dropped WITHOUT advancing sp and flagged; it cannot happen for a tree (at most three pushes per level,
+// rtk_upload.hip rejects blobs that are not trees), so a set flag means a corrupted scene, never an
+// out-of-bounds access.
+#define RTK_PUSH(e_)                                                                                        \
+	do {                                                                                                    \
+		if (sp < LDS_STACK) { stk[sp][lane] = (e_); sp++; }                                                 \
+		else if (sp - LDS_STACK < p.spill_cap) {                                                            \
+			p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane] = (e_); sp++; if (COUNT) c_spills++; \
+		} else p.counter[RTK_ERROR_WORD] = 1ull;                                                            \
+	} while (0)
+
+template <int MODE /*0 closest, 1 any*/, bool COUNT, bool FILT /*built-in candidate filters*/>
 __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 {
 	__shared__ uint2 s_stack[WAVES_PER_BLOCK][LDS_STACK][64];
@@ -101,6 +115,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 	uint32_t onx = 0, ofx = 0, ony = 0, ofy = 0, onz = 0, ofz = 0;
 	float best_t = 0, best_u = 0, best_v = 0;
 	uint32_t best_prim = RTK_PRIM_NONE;
+	float after_t = 0;                                    // FILT: candidates must come after (after_t, after_prim)
+	uint32_t after_prim = 0, skip_prim = RTK_PRIM_NONE;   // FILT: ... and must not be skip_prim
+	bool has_after = false;
 	uint32_t top = RTK_REF_NONE;
 	uint32_t sp = 0;
 	uint32_t c_nodes = 0, c_leaves = 0, c_tris = 0, c_spills = 0;
@@ -175,6 +192,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					special = !(isfinite(rdx) && isfinite(rdy) && isfinite(rdz) && rdx != 0.0f && rdy != 0.0f && rdz != 0.0f &&
 						isfinite(ox) && isfinite(oy) && isfinite(oz) && tmin_ray == tmin_ray && tmax_ray == tmax_ray);
 					best_t = tmax_ray; best_u = 0.0f; best_v = 0.0f; best_prim = RTK_PRIM_NONE;
+					if (FILT) {
+						has_after = p.after != nullptr;
+						if (has_after) { const rtk_hit_record a = p.after[ray_index]; after_t = a.t; after_prim = a.prim; has_after = a.prim != RTK_PRIM_NONE; }
+						skip_prim = p.ignore_prim ? p.ignore_prim[ray_index] : RTK_PRIM_NONE;
+					}
 					top = 0u;  // root node
 					sp = 0u;
 					active = true;
@@ -257,9 +279,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 				for (int i = 3; i >= 1; i--) {
 					if (nhit > (uint32_t)i) {
 						const uint2 e = make_uint2(__float_as_uint(key[i]), ref[i]);
-						if (sp < LDS_STACK) stk[sp][lane] = e;
-						else if (sp - LDS_STACK < p.spill_cap) { p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane] = e; if (COUNT) c_spills++; }
-						sp++;
+						RTK_PUSH(e);
 					}
 				}
 			}
@@ -338,7 +358,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 				zz = zz + w * z2;
 				const float t = zz * rcp;
 				const uint32_t prim = __float_as_uint(A.w);
-				const bool in_range = !(neg && pos) && t > tmin_ray && t < tmax_ray;   // rtk.c:354
+				bool in_range = !(neg && pos) && t > tmin_ray && t < tmax_ray;   // rtk.c:354
+				if (FILT) {
+					// built-in filters: the candidate is offered only if every filter accepts it (rtk.h:117 semantics
+					// with the filter evaluated on the device)
+					if (has_after) in_range = in_range && (t > after_t || (t == after_t && prim > after_prim));
+					in_range = in_range && prim != skip_prim;
+					if (p.mesh_mask) {
+						const uint32_t mesh = __float_as_uint(B.w) >> RTK_TRI_MESH_SHIFT;
+						in_range = in_range && mesh < p.mesh_mask_bits && ((p.mesh_mask[mesh >> 5] >> (mesh & 31u)) & 1u);
+					}
+				}
 				if (MODE == 1) {
 					if (in_range && best_prim == RTK_PRIM_NONE) { best_prim = prim; best_t = t; }
 				} else {
@@ -479,16 +509,72 @@ __global__ void rtk_expand_kernel(DevSceneView sc, const rtk_hit_record *rec, un
 // host side
 // ------------------------------------------------------------------------------------
 
-template <int MODE, bool COUNT>
-static int occupancy_blocks()
+namespace {
+
+typedef void (*trace_kernel_fn)(TraceParams);
+
+// variant index: any_hit | counted << 1 | filtered << 2
+trace_kernel_fn trace_variant(int v)
 {
-	int nb = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtk_trace_kernel<MODE, COUNT>, BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
-	return nb;
+	switch (v) {
+	case 0: return rtk_trace_kernel<0, false, false>;
+	case 1: return rtk_trace_kernel<1, false, false>;
+	case 2: return rtk_trace_kernel<0, true, false>;
+	case 3: return rtk_trace_kernel<1, true, false>;
+	case 4: return rtk_trace_kernel<0, false, true>;
+	case 5: return rtk_trace_kernel<1, false, true>;
+	case 6: return rtk_trace_kernel<0, true, true>;
+	default: return rtk_trace_kernel<1, true, true>;
+	}
+}
+
+// resident workgroups per CU of each kernel variant, per device; filled on first use
+std::mutex g_occ_mutex;
+int g_occ[RTK_MAX_DEVICES][10];
+
+int blocks_per_cu_of(int device, int variant /*0..7 per-lane, 8/9 packet plain/counted*/)
+{
+	std::lock_guard<std::mutex> lock(g_occ_mutex);
+	if (device < 0 || device >= RTK_MAX_DEVICES) device = 0;
+	int &o = g_occ[device][variant];
+	if (o == 0) {
+		int nb = 0;
+		if (variant >= 8) nb = rtk_packet_occupancy(variant == 9);
+		else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_variant(variant), BLOCK_THREADS, 0) != hipSuccess) nb = 0;
+		o = nb >= 1 ? nb : 1;
+	}
+	return o;
+}
+
+// The scratch set of (scene, stream). Called with ds->scratch_mutex held.
+LaunchScratch *scratch_for(rtk_dev_scene *ds, hipStream_t stream)
+{
+	for (LaunchScratch *s : ds->scratch) if (s->stream == stream) return s;
+	LaunchScratch *s = new LaunchScratch();
+	s->stream = stream;
+	if (hipMalloc(&s->d_counter, RTK_COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+		rtk_set_error("rtk_dev_trace: out of device memory (launch scratch)");
+		delete s;
+		return nullptr;
+	}
+	ds->scratch.push_back(s);
+	return s;
+}
+
+} // namespace
+
+void rtk_scratch_free(LaunchScratch *s)
+{
+	if (!s) return;
+	if (s->d_counter) (void)hipFree(s->d_counter);
+	if (s->d_spill) (void)hipFree(s->d_spill);
+	if (s->d_sort) (void)hipFree(s->d_sort);
+	delete s;
 }
 
 int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
-	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted)
+	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
+	const rtk_dev_filter *filter)
 {
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
 	if (!ds || (!d_rays && n) || ((any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
@@ -526,52 +612,63 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		}
 		if (opts->struct_size >= 28 && opts->node_exit) p.node_exit = opts->node_exit > 64 ? 64 : opts->node_exit;
 	}
+	bool filtered = false;
+	if (filter) {
+		if (filter->struct_size < sizeof(rtk_dev_filter)) { rtk_set_error("rtk_dev_trace: rtk_dev_filter.struct_size is too small"); return RTK_AMD_ERR_BAD_ARG; }
+		if (filter->d_mesh_mask && filter->mesh_mask_bits == 0) { rtk_set_error("rtk_dev_trace: mesh mask without mesh_mask_bits"); return RTK_AMD_ERR_BAD_ARG; }
+		p.mesh_mask = filter->d_mesh_mask;
+		p.mesh_mask_bits = filter->mesh_mask_bits;
+		p.ignore_prim = filter->d_ignore_prim;
+		p.after = filter->d_after;
+		filtered = p.mesh_mask || p.ignore_prim || p.after;
+	}
 
 	// image-shaped closest-hit batches go to the wave-packet kernel (rtk_trace_packet.hip)
-	const bool packet = !any_hit && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
-
-	static int occ[2][2] = { { 0, 0 }, { 0, 0 } };
-	static int occ_packet[2] = { 0, 0 };
-	int &o = packet ? occ_packet[counted ? 1 : 0] : occ[any_hit ? 1 : 0][counted ? 1 : 0];
-	if (o == 0) {
-		if (packet) o = rtk_packet_occupancy(counted != nullptr);
-		else o = any_hit ? (counted ? occupancy_blocks<1, true>() : occupancy_blocks<1, false>())
-		                 : (counted ? occupancy_blocks<0, true>() : occupancy_blocks<0, false>());
-	}
-	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)o) blocks_per_cu = (uint32_t)o;
+	const bool packet = !any_hit && !filtered && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
+	const int variant = packet ? (counted ? 9 : 8) : ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0));
+	const int occ = blocks_per_cu_of(ds->device, variant);
+	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
 
 	const size_t blocks_needed = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
 	size_t blocks = (p.dynamic || packet) ? (size_t)ds->num_cus * blocks_per_cu : blocks_needed;
 	if (blocks > blocks_needed) blocks = blocks_needed;
 	if (blocks > 0x7fffffffu) { rtk_set_error("rtk_dev_trace: batch too large for one launch"); return RTK_AMD_ERR_BAD_ARG; }
 
+	// From here on the launch uses the scratch set of (scene, stream); the mutex is held until everything is
+	// enqueued, so that two host threads feeding one stream cannot interleave "reset queue heads" and "launch".
+	std::lock_guard<std::mutex> lock(ds->scratch_mutex);
+	LaunchScratch *sc = scratch_for(ds, stream);
+	if (!sc) return RTK_AMD_ERR_OOM;
+
 	// spill area for rays whose stack outgrows LDS
 	const size_t lanes = blocks * BLOCK_THREADS;
 	const size_t lds_entries = packet ? 16 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
 	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
-	if (spill_cap && (ds->spill_lanes < lanes || ds->spill_entries_per_lane < spill_cap)) {
-		if (ds->d_spill) (void)hipFree(ds->d_spill);
-		ds->d_spill = nullptr;
-		RTK_HIP_CHECK(hipMalloc(&ds->d_spill, lanes * spill_cap * sizeof(uint2)), RTK_AMD_ERR_OOM);
-		ds->spill_lanes = lanes;
-		ds->spill_entries_per_lane = spill_cap;
+	if (spill_cap && (sc->spill_lanes < lanes || sc->spill_entries_per_lane < spill_cap)) {
+		// an earlier launch on this stream may still be using the old area
+		if (sc->d_spill) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_spill); }
+		sc->d_spill = nullptr;
+		sc->spill_lanes = sc->spill_entries_per_lane = 0;
+		RTK_HIP_CHECK(hipMalloc(&sc->d_spill, lanes * spill_cap * sizeof(uint2)), RTK_AMD_ERR_OOM);
+		sc->spill_lanes = lanes;
+		sc->spill_entries_per_lane = spill_cap;
 	}
 	// optional ray reordering pre-pass (per-lane kernels only)
 	p.perm = nullptr;
 	if (!packet && opts && (opts->flags & RTK_TRACE_SORT_RAYS) && n < 0x7fffffffu) {
 		const uint32_t n32 = (uint32_t)n;
 		const size_t words = rtk_sort_scratch_words(n32);
-		if (ds->sort_capacity < n) {
-			if (ds->d_sort) (void)hipFree(ds->d_sort);
-			ds->d_sort = nullptr;
-			ds->sort_capacity = 0;
+		if (sc->sort_capacity < n) {
+			if (sc->d_sort) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_sort); }
+			sc->d_sort = nullptr;
+			sc->sort_capacity = 0;
 			// [keys_a | keys_b] 8 B each, [vals_a | vals_b] 4 B each, bounds 6 words + sort scratch
-			RTK_HIP_CHECK(hipMalloc(&ds->d_sort, n * 24 + (words + 16) * 4), RTK_AMD_ERR_OOM);
-			ds->sort_capacity = n;
+			RTK_HIP_CHECK(hipMalloc(&sc->d_sort, n * 24 + (words + 16) * 4), RTK_AMD_ERR_OOM);
+			sc->sort_capacity = n;
 		}
-		unsigned long long *keys_a = (unsigned long long *)ds->d_sort, *keys_b = keys_a + ds->sort_capacity;
-		uint32_t *vals_a = (uint32_t *)(keys_b + ds->sort_capacity), *vals_b = vals_a + ds->sort_capacity;
-		uint32_t *bounds = vals_b + ds->sort_capacity, *scratch = bounds + 16;
+		unsigned long long *keys_a = (unsigned long long *)sc->d_sort, *keys_b = keys_a + sc->sort_capacity;
+		uint32_t *vals_a = (uint32_t *)(keys_b + sc->sort_capacity), *vals_b = vals_a + sc->sort_capacity;
+		uint32_t *bounds = vals_b + sc->sort_capacity, *scratch = bounds + 16;
 		static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
 		RTK_HIP_CHECK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream), RTK_AMD_ERR_HIP);
 		hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(256), 0, stream, d_rays, (unsigned long long)n, bounds);
@@ -582,31 +679,42 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		const bool in_b = rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n32, 3u * cell_bits + (with_octant ? 3u : 0u), scratch, stream);
 		p.perm = in_b ? vals_b : vals_a;
 	}
-	p.spill = ds->d_spill;
-	p.spill_stride = (uint32_t)(spill_cap ? ds->spill_lanes : 0);
+	p.spill = sc->d_spill;
+	p.spill_stride = (uint32_t)(spill_cap ? sc->spill_lanes : 0);
 	p.spill_cap = (uint32_t)spill_cap;
-	p.counter = ds->d_counter;
+	p.counter = sc->d_counter;
 
-	RTK_HIP_CHECK(hipMemsetAsync(ds->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
-	const dim3 grid((unsigned)blocks), block(BLOCK_THREADS);
-	if (packet) {
-		rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
-	} else if (any_hit) {
-		if (counted) hipLaunchKernelGGL((rtk_trace_kernel<1, true>), grid, block, 0, stream, p);
-		else hipLaunchKernelGGL((rtk_trace_kernel<1, false>), grid, block, 0, stream, p);
-	} else {
-		if (counted) hipLaunchKernelGGL((rtk_trace_kernel<0, true>), grid, block, 0, stream, p);
-		else hipLaunchKernelGGL((rtk_trace_kernel<0, false>), grid, block, 0, stream, p);
-	}
+	RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
+	else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	if (counted) {
 		unsigned long long c[16];
-		RTK_HIP_CHECK(hipMemcpyAsync(c, ds->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+		RTK_HIP_CHECK(hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
 		counted->rays = c[1]; counted->nodes = c[2]; counted->leaves = c[3];
 		counted->triangles = c[4]; counted->hits = c[5]; counted->stack_spills = c[6];
 		counted->wave_node_steps = c[7]; counted->wave_triangle_steps = c[8]; counted->wave_rays = c[9];
+		if (c[RTK_ERROR_WORD]) { rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)"); return RTK_AMD_ERR_BAD_SCENE; }
 	}
+	return RTK_AMD_OK;
+}
+
+// Did any launch of this scene on `stream` since the last call overflow a traversal stack? Synchronises the stream.
+int rtk_trace_status(const rtk_dev_scene *ds_c, hipStream_t stream)
+{
+	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
+	if (!ds) { rtk_set_error("rtk_dev_trace_status: NULL scene"); return RTK_AMD_ERR_BAD_ARG; }
+	std::lock_guard<std::mutex> lock(ds->scratch_mutex);
+	for (LaunchScratch *s : ds->scratch) {
+		if (s->stream != stream) continue;
+		unsigned long long e = 0;
+		RTK_HIP_CHECK(hipMemcpyAsync(&e, s->d_counter + RTK_ERROR_WORD, sizeof(e), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
+		if (e) { rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)"); return RTK_AMD_ERR_BAD_SCENE; }
+		return RTK_AMD_OK;
+	}
+	RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
 }
 

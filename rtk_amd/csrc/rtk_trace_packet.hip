@@ -229,6 +229,21 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 	}
 }
 
+// Push one child: its reference into the wave-uniform stack register, every lane's own entry distance into
+// LDS (or the spill area). A push that does not fit (impossible for a tree: the launcher refuses scenes
+// needing more than PK_WAVE_STACK entries and sizes the spill area from the depth) is dropped without
+// advancing sp, and flagged.
+#define PK_PUSH(dist_, ref_)                                                                                      \
+	do {                                                                                                          \
+		const bool in_lds_ = sp < PK_LDS_STACK;                                                                   \
+		if (sp < PK_WAVE_STACK && (in_lds_ || sp - PK_LDS_STACK < p.spill_cap)) {                                 \
+			if (in_lds_) lds_t[sp][lane] = (dist_);                                                               \
+			else { spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane] = (dist_); if (COUNT) c_spills++; } \
+			stack = stack_write(stack, (ref_), sp, lane);                                                         \
+			sp++;                                                                                                 \
+		} else if (lane == 0) p.counter[RTK_ERROR_WORD] = 1ull;                                                   \
+	} while (0)
+
 template <bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_packet_kernel(TraceParams p)
 {
@@ -355,10 +370,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
 					const bool swap = k1 < k0;
 					const float pfar = swap ? p0 : p1, pnear = swap ? p1 : p0;
-					if (sp < PK_LDS_STACK) lds_t[sp][lane] = pfar;
-					else if (sp - PK_LDS_STACK < p.spill_cap) { spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane] = pfar; if (COUNT) c_spills++; }
-					stack = stack_write(stack, swap ? r0 : r1, sp, lane);
-					sp++;
+					PK_PUSH(pfar, swap ? r0 : r1);
 					live = pnear == pnear;
 					top = swap ? r1 : r0;
 				} else {
@@ -381,10 +393,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 #pragma unroll
 					for (int i = 3; i >= 1; i--) {
 						if (n_any > (uint32_t)i) {
-							if (sp < PK_LDS_STACK) lds_t[sp][lane] = pay[i];
-							else if (sp - PK_LDS_STACK < p.spill_cap) { spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane] = pay[i]; if (COUNT) c_spills++; }
-							stack = stack_write(stack, ref[i], sp, lane);
-							sp++;
+							PK_PUSH(pay[i], ref[i]);
 						}
 					}
 					live = pay[0] == pay[0];

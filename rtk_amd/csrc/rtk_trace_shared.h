@@ -25,7 +25,15 @@ struct TraceParams {
 	uint32_t dynamic;
 	uint32_t node_exit;            // leave the node loop when fewer lanes than this still need node steps and a leaf is waiting
 	const uint32_t *perm;          // optional: trace rays in this order (ray reordering), results go to the ray's own slot
+	// built-in candidate filters (rtk_dev_filter, FILT kernels only); all optional
+	const rtk_hit_record *after;   // per ray: only candidates that come after (t, prim) in (t, prim) order
+	const uint32_t *ignore_prim;   // per ray: global primitive id that is never a candidate
+	const uint32_t *mesh_mask;     // bit m set = triangles of mesh m are candidates
+	uint32_t mesh_mask_bits;       // meshes covered by mesh_mask; meshes beyond it are not candidates
 };
+
+// DevTri.flags: bit 0 = last triangle of its leaf, bits 8.. = mesh index (for the mesh-mask filter)
+#define RTK_TRI_MESH_SHIFT 8
 
 // _mm_min_ps/_mm_max_ps semantics (second operand when the compare is false, NaN included)
 __device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }

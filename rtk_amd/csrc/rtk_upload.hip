@@ -39,7 +39,9 @@ bool slot_is_empty(const BlobNode &n, int i)
 
 } // namespace
 
-int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out)
+// `avail`: bytes that are known to be readable at `scene` (the loader of an untrusted file passes the
+// file size; callers that only have the reference's bare rtk_scene* pass size_in_bytes itself).
+int rtk_blob_to_host_bvh(const rtk_scene *scene, size_t avail, HostBvh *out)
 {
 	static const char magic[8] = { 0, 'R', 'T', 'K', '\r', '\n', 0x1a, '\n' };
 	if (!scene) { rtk_set_error("scene is NULL"); return RTK_AMD_ERR_BAD_ARG; }
@@ -47,10 +49,14 @@ int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out)
 	if (scene->endian != 0xaabb) { rtk_set_error("scene blob: foreign endianness"); return RTK_AMD_ERR_BAD_SCENE; }
 	if (scene->sizeof_real != 4 || scene->version != 1) { rtk_set_error("scene blob: unsupported sizeof_real/version"); return RTK_AMD_ERR_BAD_SCENE; }
 	const uint64_t size = scene->size_in_bytes;
-	if (size < 256 || scene->node_offset != 128) { rtk_set_error("scene blob: bad size or node offset"); return RTK_AMD_ERR_BAD_SCENE; }
+	if (size < 256 || size > ((uint64_t)1 << 48) || scene->node_offset != 128) { rtk_set_error("scene blob: bad size or node offset"); return RTK_AMD_ERR_BAD_SCENE; }
+	if (size > avail) { rtk_set_error("scene blob: header claims %llu bytes, only %zu are there", (unsigned long long)size, avail); return RTK_AMD_ERR_BAD_SCENE; }
 	const char *blob = reinterpret_cast<const char *>(scene);
 
-	// pass 1: breadth-first walk; number nodes, collect leaves
+	// pass 1: breadth-first walk; number nodes, collect leaves. All range checks are written so that they
+	// cannot wrap (offsets come from the file and may be anything up to 2^64-1). A blob must be a TREE: a
+	// node or a non-empty leaf that is reached twice (shared subtree, or a child pointing back at an
+	// ancestor) is refused -- the traversal stacks are sized from the depth of a tree.
 	std::unordered_map<uint64_t, uint32_t> node_index;   // blob offset -> device node index
 	std::unordered_map<uint64_t, uint32_t> leaf_index;   // blob offset -> index into leaves
 	std::vector<uint64_t> node_offsets;
@@ -63,27 +69,29 @@ int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out)
 	uint64_t total_tris = 0;
 	for (size_t qi = 0; qi < node_offsets.size(); qi++) {
 		const uint64_t off = node_offsets[qi];
-		if (off + sizeof(BlobNode) > size) { rtk_set_error("scene blob: node at %llu out of range", (unsigned long long)off); return RTK_AMD_ERR_BAD_SCENE; }
 		BlobNode n;
-		memcpy(&n, blob + off, sizeof(n));
+		memcpy(&n, blob + off, sizeof(n));                // off was range-checked when it was queued (root: size >= 256)
 		for (int i = 0; i < 4; i++) {
 			if (slot_is_empty(n, i)) continue;
 			const uint64_t p = n.child[i];
 			if (p & 1u) {
 				const uint64_t lo = p ^ 1u;
-				if (lo + 8 > size) { rtk_set_error("scene blob: leaf at %llu out of range", (unsigned long long)lo); return RTK_AMD_ERR_BAD_SCENE; }
-				if (leaf_index.count(lo)) continue;
+				if (lo < 128 || lo > size - 8) { rtk_set_error("scene blob: leaf at %llu out of range", (unsigned long long)lo); return RTK_AMD_ERR_BAD_SCENE; }
 				uint64_t info;
 				memcpy(&info, blob + lo, 8);
 				const uint32_t cnt = (uint32_t)(info & 0x3f);
 				const uint64_t n4 = (cnt + 3u) & ~3ull;
-				if (lo + 8 + 8 * n4 > size) { rtk_set_error("scene blob: leaf triangles out of range"); return RTK_AMD_ERR_BAD_SCENE; }
+				if (8 * n4 > size - lo - 8) { rtk_set_error("scene blob: leaf triangles out of range"); return RTK_AMD_ERR_BAD_SCENE; }
+				if (leaf_index.count(lo)) {
+					if (cnt) { rtk_set_error("scene blob: leaf at %llu is referenced twice (not a tree)", (unsigned long long)lo); return RTK_AMD_ERR_BAD_SCENE; }
+					continue;
+				}
 				leaf_index[lo] = (uint32_t)leaves.size();
 				leaves.push_back(LeafRef{ lo, cnt, 0 });
 				total_tris += cnt;
 			} else {
-				if (node_index.count(p)) continue;
-				if (node_offsets.size() >= size / sizeof(BlobNode)) { rtk_set_error("scene blob: more nodes than fit the blob"); return RTK_AMD_ERR_BAD_SCENE; }
+				if (p < 128 || (p & 127u) || p > size - sizeof(BlobNode)) { rtk_set_error("scene blob: node at %llu out of range or misaligned", (unsigned long long)p); return RTK_AMD_ERR_BAD_SCENE; }
+				if (node_index.count(p)) { rtk_set_error("scene blob: node at %llu is referenced twice (shared subtree or cycle)", (unsigned long long)p); return RTK_AMD_ERR_BAD_SCENE; }
 				node_index[p] = (uint32_t)node_offsets.size();
 				node_offsets.push_back(p);
 				node_depth.push_back(node_depth[qi] + 1);
@@ -102,8 +110,8 @@ int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out)
 		for (uint32_t i = 0; i < lf.count; i++) {
 			BlobLeafTri t;
 			memcpy(&t, lt + i, 8);
-			const uint64_t at = (uint64_t)(table - blob) + 4ull * t.local_mesh;
-			if (at + 4 > size) { rtk_set_error("scene blob: mesh table out of range"); return RTK_AMD_ERR_BAD_SCENE; }
+			const uint64_t at = (uint64_t)(table - blob) + 4ull * t.local_mesh;     // <= size + 1020: cannot wrap
+			if (at > size - 4) { rtk_set_error("scene blob: mesh table out of range"); return RTK_AMD_ERR_BAD_SCENE; }
 			uint32_t mesh;
 			memcpy(&mesh, blob + at, 4);
 			if (mesh >= (1u << 24)) { rtk_set_error("scene blob: implausible mesh index %u", mesh); return RTK_AMD_ERR_BAD_SCENE; }
@@ -137,15 +145,15 @@ int rtk_blob_to_host_bvh(const rtk_scene *scene, HostBvh *out)
 			DevTri &d = out->tris[slot];
 			float *dst[3] = { d.v0, d.v1, d.v2 };
 			for (int c = 0; c < 3; c++) {
+				if (vg > size - 16 || 16ull * t.v[c] > size - 16 - vg) { rtk_set_error("scene blob: vertex out of range"); return RTK_AMD_ERR_BAD_SCENE; }
 				const uint64_t at = vg + 16ull * t.v[c];
-				if (at + 16 > size) { rtk_set_error("scene blob: vertex out of range"); return RTK_AMD_ERR_BAD_SCENE; }
 				rtk_vertex v;
 				memcpy(&v, blob + at, 16);
 				dst[c][0] = v.position.x; dst[c][1] = v.position.y; dst[c][2] = v.position.z;
 				out->vertex_index[3 * (size_t)slot + c] = v.index;
 			}
 			d.prim = (uint32_t)(out->mesh_base[mesh] + t.triangle_index);
-			d.flags = (i + 1 == lf.count) ? RTK_TRI_LAST : 0u;
+			d.flags = ((i + 1 == lf.count) ? RTK_TRI_LAST : 0u) | (mesh << 8);   // RTK_TRI_MESH_SHIFT
 			d.spare = (i == 0) ? lf.count : 0u;   // leaf size rides in the first record
 			out->slot_mesh[slot] = mesh;
 			out->slot_tri[slot] = t.triangle_index;
@@ -217,7 +225,6 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h)
 	bool ok = upload_vec(ds, h.nodes, &ds->view.nodes) && upload_vec(ds, h.tris, &ds->view.tris) &&
 		upload_vec(ds, h.vertex_index, &ds->view.vertex_index) && upload_vec(ds, prim_slot, &ds->view.prim_slot) &&
 		upload_vec(ds, h.slot_mesh, &ds->view.slot_mesh) && upload_vec(ds, h.slot_tri, &ds->view.slot_tri);
-	if (ok) ok = hipMalloc(&ds->d_counter, RTK_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess;
 	if (!ok) {
 		rtk_set_error("device allocation/copy failed: %s", hipGetErrorString(hipGetLastError()));
 		rtk_dev_scene_free(ds);

@@ -94,6 +94,32 @@ def test_blob_validator_rejects_corrupt_scenes_without_a_gpu(oracle):
     info = int(bad[first_leaf:first_leaf + 8].view(np.uint64)[0])
     bad[first_leaf:first_leaf + 8] = np.frombuffer(np.uint64((info & 0x3f) | ((hdr.size_in_bytes * 2) & ~0x3f)).tobytes(), np.uint8)
     h, err = upload(bad); assert not h and "vertex" in err
+    # offsets near 2^64 must not wrap around the range checks
+    bad = good.copy(); bad[128 + 96:128 + 104] = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFF80).tobytes(), np.uint8)
+    h, err = upload(bad); assert not h and "out of range" in err
+    bad = good.copy(); bad[128 + 96:128 + 104] = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFFF9).tobytes(), np.uint8)   # leaf-tagged
+    h, err = upload(bad); assert not h and "out of range" in err
+    bad = good.copy()
+    bad[first_leaf:first_leaf + 8] = np.frombuffer(np.uint64((info & 0x3f) | 0xFFFFFFFFFFFFFFC0).tobytes(), np.uint8)
+    h, err = upload(bad); assert not h and "vertex" in err
+    # a misaligned node pointer
+    inner = [int(p) for p in nodes[0, 12:16] if (int(p) & 1) == 0]
+    assert inner, "root has no inner child"
+    bad = good.copy()
+    slot = [k for k in range(4) if int(nodes[0, 12 + k]) == inner[0]][0]
+    bad[128 + 96 + 8 * slot:128 + 104 + 8 * slot] = np.frombuffer(np.uint64(inner[0] + 8).tobytes(), np.uint8)
+    h, err = upload(bad); assert not h and "misaligned" in err
+    # not a tree: a child pointing back at the root (cycle), and one inner node referenced by two slots (DAG)
+    bad = good.copy(); bad[128 + 96 + 8 * slot:128 + 104 + 8 * slot] = np.frombuffer(np.uint64(128).tobytes(), np.uint8)
+    h, err = upload(bad); assert not h and "twice" in err
+    if len(inner) >= 2:
+        other = [k for k in range(4) if int(nodes[0, 12 + k]) == inner[1]][0]
+        bad = good.copy(); bad[128 + 96 + 8 * other:128 + 104 + 8 * other] = np.frombuffer(np.uint64(inner[0]).tobytes(), np.uint8)
+        h, err = upload(bad); assert not h and "twice" in err
+    # the sized loader also refuses a header that claims more bytes than the file has
+    a = np.ascontiguousarray(good)
+    h = L.rtk_dev_scene_upload_buffer(C.c_void_p(a.ctypes.data), a.size - 64)
+    assert not h and "only" in api.last_error()
     if not torch.cuda.is_available():
         h, err = upload(good)
         assert not h and "HIP device" in err

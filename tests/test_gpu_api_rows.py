@@ -148,3 +148,201 @@ def test_error_paths_are_loud(api):
     assert L.rtk_dev_scene_export(ds.handle, None, 0) is None
     small = np.zeros(16, np.uint8)
     assert L.rtk_dev_scene_export(ds.handle, small.ctypes.data, small.size) is None
+
+
+def test_equal_t_candidates_are_all_offered(api, golden_dir):
+    """The edge scene holds exact duplicates (primitives 0, 8 and 9 are the same triangle): a filter that rejects
+    the first two must still be offered the third at the SAME t, in primitive-id order."""
+    from tests.util import load_golden
+    g = load_golden(golden_dir, "edge_cases.npz")
+    tris = g["tris"].reshape(-1, 3, 3)
+    dup = [i for i in range(len(tris)) if (tris[i] == tris[0]).all()]
+    assert dup == [0, 8, 9]
+    scene, keep = api.build_scene([dict(positions=g["tris"].reshape(-1, 3))])
+    try:
+        c = tris[0].mean(axis=0)
+        ray = np.zeros(1, RAY_DTYPE)
+        ray["origin"] = c + np.array([0.01, -0.02, 1.0], np.float32)
+        ray["direction"] = -np.array([0.01, -0.02, 1.0], np.float32)
+        ray["max_t"] = 10.0
+        offered = []
+
+        def reject_first(k):
+            def f(i, hit):
+                offered.append((int(hit["triangle_index"]), float(hit["t"])))
+                return len(offered) > k
+            return f
+        for k in range(3):
+            offered.clear()
+            hits, mask = api.trace_rays_filter(scene, ray, reject_first(k))
+            assert mask[0] and hits["triangle_index"][0] == dup[k]
+            assert [o[0] for o in offered] == dup[:k + 1]
+            assert len({o[1] for o in offered}) == 1                 # one and the same t
+        # the single-ray entry point goes the same way
+        L = api.lib()
+        offered.clear()
+        cb = FILTER_CB(lambda user, r, h: (offered.append(1) or len(offered) > 2))
+        out = np.zeros(1, HIT_DTYPE)
+        assert L.rtk_trace_ray_filter(C.c_void_p(scene), ray.ctypes.data, out.ctypes.data, C.cast(cb, C.c_void_p), None)
+        assert out["triangle_index"][0] == 9 and len(offered) == 3
+    finally:
+        api.free_scene(scene)
+
+
+def test_host_filter_batch_equals_oracle(api, oracle):
+    """rtk_trace_rays_filter on a batch: same answer as the oracle driven with the same predicate."""
+    tris = synth.scene_for_config(1)
+    scene, keep = api.build_scene([dict(positions=tris)])
+    try:
+        rays = synth.rays_config1(2048)
+        pred = lambda i, hit: (int(hit["triangle_index"]) * 2654435761 >> 7) % 3 != 0   # rejects a third of all primitives
+        hits, mask = api.trace_rays_filter(scene, rays, pred)
+        blob = oracle.Blob(np.ascontiguousarray(api.scene_bytes(scene)))
+        oh, om = oracle.trace_filtered(blob, rays, callback=pred)
+        assert (mask == om).all() and mask.sum() > 500
+        assert (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+        assert (hits["t"][mask] == oh["t"][om]).all() and (hits["u"][mask] == oh["u"][om]).all()
+        plain, pm = api.trace_rays(scene, rays)
+        assert (hits["t"][mask] >= plain["t"][mask]).all() and (hits["triangle_index"][mask] != plain["triangle_index"][mask]).any()
+    finally:
+        api.free_scene(scene)
+
+
+def test_device_filters_equal_oracle(api, oracle):
+    """Built-in device filters (rtk_dev_filter): mesh mask, per-ray ignored primitive, (t, prim) continuation --
+    closest-hit and any-hit -- against the oracle driven with the equivalent filter on the exported blob."""
+    a = synth.triangle_soup(4000, 0.08, seed=31)
+    b = synth.triangle_soup(3000, 0.08, seed=32)
+    c = synth.triangle_soup(2000, 0.08, seed=33)
+    ds = api.DeviceScene.build([dict(positions=a), dict(positions=b), dict(positions=c)])
+    base = ds.mesh_base()
+    blob = oracle.Blob(ds.export_blob())
+    rays = synth.rays_config1(8192)
+    plain = ds.trace(rays, full=False)
+    hit = plain["prim"] != 0xFFFFFFFF
+
+    def check(rec, oh, om, what):
+        gm = rec["prim"] != 0xFFFFFFFF
+        assert (gm == om).all(), what
+        oprim = base[oh["mesh_index"][om].astype(np.int64)] + oh["triangle_index"][om]
+        assert (rec["prim"][gm] == oprim).all(), what
+        assert (rec["t"][gm] == oh["t"][om]).all() and (rec["u"][gm] == oh["u"][om]).all() and (rec["v"][gm] == oh["v"][om]).all(), what
+
+    # mesh mask: only meshes 0 and 2 visible
+    vis = [True, False, True]
+    rec = ds.trace_filtered(rays, mesh_mask=vis)
+    oh, om = oracle.trace_filtered(blob, rays, mesh_mask=vis)
+    check(rec, oh, om, "mesh mask")
+    mesh_of = np.searchsorted(base, rec["prim"][rec["prim"] != 0xFFFFFFFF], side="right") - 1
+    assert (mesh_of != 1).all() and (rec["prim"] != plain["prim"]).any()
+    assert (ds.trace_filtered(rays, mesh_mask=vis, any_hit=True) == om).all()
+    # a mask that covers fewer meshes than the scene has: the uncovered mesh is invisible
+    rec2 = ds.trace_filtered(rays, mesh_mask=[True, False])
+    oh2, om2 = oracle.trace_filtered(blob, rays, mesh_mask=[True, False, False])
+    check(rec2, oh2, om2, "short mesh mask")
+
+    # ignore the primitive each ray hit first -> the second closest candidate
+    ig = plain["prim"].copy()
+    rec = ds.trace_filtered(rays, ignore_prim=ig)
+    pm = np.where(hit, np.searchsorted(base, np.where(hit, plain["prim"], 0), side="right") - 1, 0xFFFFFFFF).astype(np.uint32)
+    pt = np.where(hit, plain["prim"] - base[np.where(hit, pm, 0).astype(np.int64)], 0).astype(np.uint32)
+    oh, om = oracle.trace_filtered(blob, rays, ignore=(pm, pt))
+    check(rec, oh, om, "ignore primitive")
+    assert ((rec["prim"] != plain["prim"]) | ~hit).all()
+
+    # continuation: candidates after the first hit = the same second candidate (no two candidates tie here)
+    rec3 = ds.trace_filtered(rays, after=plain)
+    assert rec3.tobytes() == rec.tobytes()
+    oh, om = oracle.trace_filtered(blob, rays, after=(plain["t"], pm, pt))
+    check(rec3, oh, om, "after")
+    # enumerating with `after` until exhaustion visits candidates in strictly increasing (t, prim) order
+    cur, steps = plain.copy(), 0
+    while (cur["prim"] != 0xFFFFFFFF).any() and steps < 64:
+        nxt = ds.trace_filtered(rays, after=cur)
+        live = nxt["prim"] != 0xFFFFFFFF
+        assert ((nxt["t"][live] > cur["t"][live]) | ((nxt["t"][live] == cur["t"][live]) & (nxt["prim"][live] > cur["prim"][live]))).all()
+        assert (cur["prim"][live] != 0xFFFFFFFF).all()              # a ray that ran out stays out
+        cur, steps = nxt, steps + 1
+    assert 3 < steps < 64
+
+
+def test_one_scene_traced_from_many_threads(api, oracle):
+    """rtk_trace_rays / rtk_trace_ray from 6 host threads on ONE cached scene, and rtk_dev_trace_rays on 4
+    streams at once: every result equals the single-threaded one (per-(scene, stream) launch scratch)."""
+    import threading
+    import torch
+    tris = synth.scene_for_config(1)
+    scene, keep = api.build_scene([dict(positions=tris)])
+    try:
+        rays = synth.rays_config1(65536)
+        want_hits, want_mask = api.trace_rays(scene, rays)
+        results, errors = {}, []
+
+        def worker(k):
+            try:
+                for rep in range(4):
+                    sl = slice(k * 8192, (k + 1) * 8192 + rep * 1000)
+                    h, m = api.trace_rays(scene, rays[sl])
+                    if not ((m == want_mask[sl]).all() and (h["triangle_index"][m] == want_hits["triangle_index"][sl][m]).all()
+                            and (h["t"][m] == want_hits["t"][sl][m]).all()):
+                        errors.append(("batch", k, rep))
+                for i in range(k * 50, k * 50 + 50):
+                    one = api.trace_ray(scene, rays[i])
+                    if (one is not None) != bool(want_mask[i]) or (one is not None and one["triangle_index"] != want_hits["triangle_index"][i]):
+                        errors.append(("single", k, i))
+                results[k] = True
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors and len(results) == 6, errors[:4]
+    finally:
+        api.free_scene(scene)
+    # device-pointer API on several streams at once
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    big = np.concatenate([synth.rays_config1(65536, seed=s) for s in (2, 7, 8, 9)])
+    want = ds.trace(big, full=False)
+    d_rays = api.to_device(big)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [torch.zeros(65536 * 16, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                ds.trace_device(d_rays[k * 65536 * 32:(k + 1) * 65536 * 32], 65536, outs[k])
+    torch.cuda.synchronize()
+    got = np.concatenate([o.cpu().numpy() for o in outs])
+    assert got.tobytes() == want.tobytes()
+
+
+def test_residency_cache_notices_a_new_blob_at_the_same_address(api, oracle):
+    """rtk_finish_build_to writes into caller memory; a caller that reuses the buffer for another scene must get
+    the new scene traced, not the cached device copy of the old one."""
+    from rtk_amd.types import MeshSet
+    L = api.lib()
+    rays = synth.rays_config1(2048)
+    buf = oracle._aligned_bytes(4 << 20)
+    answers = []
+    for seed in (41, 42):
+        tris = synth.triangle_soup(3000, 0.1, seed=seed)
+        ms = MeshSet([dict(positions=tris)])
+        b = L.rtk_start_build(C.byref(ms.desc), None)
+        assert b
+        size = L.rtk_get_build_size(b)
+        assert 0 < size <= buf.size
+        s = L.rtk_finish_build_to(b, buf.ctypes.data, buf.size)
+        assert s == buf.ctypes.data
+        hits, mask = api.trace_rays(s, rays)
+        oh, om = oracle.trace(oracle.Blob(buf[:size]), rays)
+        assert (mask == om).all() and (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+        answers.append(hits["t"][mask].tobytes())
+    assert answers[0] != answers[1]
+    # a blob copied over the old one by plain memcpy (no library call at all) is noticed too
+    tris = synth.triangle_soup(3000, 0.1, seed=43)
+    blob = oracle.build_scene([dict(positions=tris)])
+    buf[:blob.size] = blob.data
+    hits, mask = api.trace_rays(buf.ctypes.data, rays)
+    oh, om = oracle.trace(blob, rays)
+    assert (mask == om).all() and (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+    L.rtk_amd_forget_scene(C.c_void_p(buf.ctypes.data))

@@ -209,7 +209,8 @@ def test_device_resident_mesh_is_read_in_place(api, oracle):
 
 
 def _morton_keys(tris):
-    """63-bit Morton keys exactly as rtk_build.hip's k_bounds/k_morton compute them (float32 ops)."""
+    """Morton keys exactly as rtk_build.hip's k_bounds/k_morton compute them (float32 ops): 63 bits, of which
+    the builder keeps the top 48 for scenes below 2^24 triangles."""
     t = tris.reshape(-1, 3, 3)
     c2 = (t.min(axis=1) + t.max(axis=1)).astype(np.float32)
     lo, hi = c2.min(axis=0), c2.max(axis=0)
@@ -226,7 +227,8 @@ def _morton_keys(tris):
         v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
         v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
         return v
-    return (spread(q[:, 0]) << np.uint64(2)) | (spread(q[:, 1]) << np.uint64(1)) | spread(q[:, 2])
+    k = (spread(q[:, 0]) << np.uint64(2)) | (spread(q[:, 1]) << np.uint64(1)) | spread(q[:, 2])
+    return k >> np.uint64(15) if len(t) < (1 << 24) else k
 
 
 @pytest.mark.parametrize("n", [1000, 4096, 4097, 70001, 1_000_000])
@@ -241,3 +243,82 @@ def test_radix_sort_leaves_triangles_in_morton_order(api, n):
     assert (keys[1:] >= keys[:-1]).all()
     same = keys[1:] == keys[:-1]
     assert (order[1:][same] > order[:-1][same]).all()
+
+
+@pytest.mark.parametrize("n,spread", [(2, 0.5), (3, 0.5), (1023, 0.1), (1024, 0.1), (1025, 0.1), (10_000, 0.05), (1_000_000, 0.02)])
+def test_device_bvh_is_structurally_valid_and_reproducible(api, n, spread):
+    """The device validator (independent of any traversal): every child box is the exact union of what is below
+    it, every triangle sits in exactly one leaf, every node is referenced once; two builds of the same input are
+    byte-identical (content hash over nodes and triangle records; at small sizes also the exported blobs).
+    Sizes straddle the refit tile (1024 sorted triangles per workgroup) so that both refit passes are exercised."""
+    tris = synth.triangle_soup(n, spread, seed=17)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert ok, c
+    assert c["triangles_checked"] == n and c["nodes_checked"] == ds.info()["num_nodes"]
+    assert c["loose_boxes"] == 0 and c["first_bad_index"] == 2 ** 64 - 1
+    ds2 = api.DeviceScene.build([dict(positions=tris)])
+    ok2, c2 = ds2.validate()
+    assert ok2 and c2["content_hash"] == c["content_hash"] and c2["nodes_checked"] == c["nodes_checked"]
+    if n <= 10_000:
+        assert ds.export_blob().tobytes() == ds2.export_blob().tobytes()
+    # a different input gives a different hash (the hash is not vacuous)
+    other = tris.copy(); other[0, 0] += np.float32(1e-3)
+    assert api.DeviceScene.build([dict(positions=other)]).validate()[1]["content_hash"] != c["content_hash"]
+
+
+def test_validator_sees_a_wrong_box_and_a_lost_triangle(api, oracle):
+    """Negative control: a blob whose root child box was shrunk, and one whose leaf lost a triangle, fail."""
+    tris = synth.triangle_soup(300, 0.2, seed=4)
+    blob = oracle.build_scene([dict(positions=tris)])
+    ok, c = api.DeviceScene.upload(blob).validate()
+    assert ok and c["triangles_checked"] == 300, c
+    bad = blob.data.copy()
+    bx = bad[128:128 + 32].view(np.float32)         # bounds_x[min][4], bounds_x[max][4] of the root
+    bx[4] = bx[0] + (bx[4] - bx[0]) * 0.5           # halve the x extent of child 0
+    ok, c = api.DeviceScene.upload(bad).validate()
+    assert not ok and c["box_violations"] >= 1 and c["first_bad_index"] == 0
+
+
+@pytest.mark.slow
+def test_config5_device_bvh_is_structurally_valid_and_reproducible(api):
+    tris = synth.scene_for_config(5)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert ok and c["triangles_checked"] == 10_000_000 and c["loose_boxes"] == 0, c
+    h = c["content_hash"]
+    ds.free()
+    ds2 = api.DeviceScene.build([dict(positions=tris)])
+    assert ds2.validate()[1]["content_hash"] == h
+
+
+def test_default_index_type_means_u32(api):
+    """rtk_mesh.index.type == RTK_TYPE_DEFAULT with an index buffer: 32-bit indices (rtk.c:1049-1059)."""
+    from rtk_amd.types import Mesh, SceneDesc, RTK_TYPE_DEFAULT, RTK_TYPE_U32
+    tris = synth.triangle_soup(700, 0.1, seed=8)
+    verts, inv = np.unique(tris, axis=0, return_inverse=True)
+    idx = np.ascontiguousarray(inv.reshape(-1, 3).astype(np.uint32))
+    verts = np.ascontiguousarray(verts.astype(np.float32))
+    rays = synth.rays_config1(4096)
+    recs = []
+    for ty in (RTK_TYPE_DEFAULT, RTK_TYPE_U32):
+        m = Mesh()
+        m.num_triangles = len(idx)
+        m.position.data = verts.ctypes.data
+        m.position.type = RTK_TYPE_DEFAULT          # float32, tightly packed
+        m.index.data = idx.ctypes.data
+        m.index.type = ty
+        arr = (Mesh * 1)(m)
+        desc = SceneDesc()
+        desc.meshes = C.cast(arr, C.POINTER(Mesh))
+        desc.num_meshes = 1
+        h = api.lib().rtk_dev_scene_build(C.byref(desc))
+        assert h, api.last_error()
+        ds = api.DeviceScene(h, keepalive=(arr, verts, idx))
+        assert ds.validate()[0]
+        recs.append(ds.trace(rays, full=False).tobytes())
+    assert recs[0] == recs[1]
+    ref = api.DeviceScene.build([dict(positions=tris)])
+    a = np.frombuffer(recs[0], dtype=ref.trace(rays, full=False).dtype)
+    b = ref.trace(rays, full=False)
+    assert (a["prim"] == b["prim"]).all() and (a["t"] == b["t"]).all()
