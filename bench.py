@@ -11,9 +11,12 @@ Rays, BVH and hit records are resident in HBM for the whole timed region. The BV
 built on the GPU by the product path (rtk_dev_scene_build) before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): whole-job Mrays/s, plus
-  roofline:     algorithmic bytes of the traversal kernel / its measured duration vs 8 TB/s
+  roofline:     algorithmic bytes of the traversal kernel per unit it actually fetches for (a 64-ray tile for
+                the packet kernel, a ray for the per-lane kernels) / its measured duration vs 8 TB/s, the
+                fabric traffic of the same launch from the committed rocprofv3 PMC summary, and the kernel's
+                real limiter (VALU issue / lane utilisation) from the same counters
   cpu_baseline: the CPU oracle (a port of rtk.c's trace path) timed on this host's cores,
-                with the parity of the timed GPU result against it.
+                with the parity of the timed GPU result against it (every id mismatch is listed).
 
 Other BASELINE.json configs (parity-test cases, not the headline line):
   --workload incoherent   config 3: 2^24 random rays on the same scene
@@ -38,6 +41,59 @@ NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 32, 16
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+KERNEL_SOURCES = ["rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h",
+                  "rtk_amd/csrc/rtk_dev.h"]
+CLOCK_GHZ = 2.4                 # MI355X max engine clock (MI355X_MICROARCH.md); the clock held under load is lower
+SIMDS = 256 * 4
+
+
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_summary(workload):
+    """Newest committed rocprofv3 PMC summary of this workload (profiles/rNN_<workload>_lbvh_pmc.json), and whether it
+    was measured on the traversal kernels as they are now (scripts/summarize_profile.py records their source hash)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_lbvh_pmc.json" % workload)), reverse=True):
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if "hbm_traffic_bytes_per_launch" not in pj:
+            continue
+        return pj, os.path.relpath(f, ROOT), pj.get("kernel_source_sha16") == kernel_source_sha16()
+    return None, None, False
+
+
+def limiter_from_pmc(pj):
+    """What the counters say bounds the kernel: share of cycles the VALU pipes are issuing, lane utilisation of
+    those instructions, share of wave time spent waiting, L2 hit rate."""
+    c = pj.get("pmc_per_launch", {})
+    ns = pj.get("kernel_trace", {}).get("average_ns")
+
+    def m(k):
+        return c[k]["mean"] if k in c else None
+    out = {}
+    if m("SQ_ACTIVE_INST_VALU") and ns:
+        # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs (MI355X_MICROARCH.md, cycle constants)
+        out["valu_busy"] = round(m("SQ_ACTIVE_INST_VALU") * 4.0 / (SIMDS * ns * CLOCK_GHZ), 3)
+    if m("SQ_THREAD_CYCLES_VALU") and m("SQ_ACTIVE_INST_VALU"):
+        out["valu_lane_utilisation"] = round(m("SQ_THREAD_CYCLES_VALU") / (64.0 * m("SQ_ACTIVE_INST_VALU")), 3)
+    if m("SQ_WAIT_ANY") and m("SQ_WAVE_CYCLES"):
+        out["wave_cycles_waiting"] = round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 3)
+    if "l2_hit_rate" in pj:
+        out["l2_hit_rate"] = round(pj["l2_hit_rate"], 3)
+    return out
+
+
+def f32_ulps(a, b):
+    return int(abs(int(np.float32(a).view(np.int32)) - int(np.float32(b).view(np.int32))))
 
 
 def main():
@@ -203,7 +259,16 @@ def main():
 
     # ---- algorithmic bytes from the counting build (not timed) ----------------------------
     _, ctr = ds.trace_any_counted(rays, opts) if shadow else ds.trace_counted(rays, opts)
-    alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
+    packet_kernel = args.workload == "coherent" and not args.no_tiling and not args.no_packet and not DRY
+    # SURVEY.md section 8d per unit the kernel actually fetches for: the packet kernel fetches a node / triangle ONCE
+    # per 64-ray tile (scalar cache), the per-lane kernels once per ray.
+    per_ray_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
+    if packet_kernel:
+        alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["wave_node_steps"] * NODE_BYTES + ctr["wave_triangle_steps"] * TRI_BYTES
+        unit = "tile of 64 rays: each node (128 B) and triangle (48 B) is fetched once per tile through the scalar cache"
+    else:
+        alg_bytes = per_ray_bytes
+        unit = "ray: each lane fetches its own nodes (128 B) and triangles (48 B)"
     sync()
 
     for k in range(args.warmup):
@@ -270,22 +335,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    # HBM traffic of the same launch from the committed rocprofv3 PMC summary (separate passes; see
-    # scripts/profile_round1.sh + scripts/summarize_profile.py), newest file first
-    traffic, traffic_src = None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_lbvh_pmc.json" % args.workload)), reverse=True):
-        try:
-            pj = json.load(open(f))
-            if args.bvh == "device" and "hbm_traffic_bytes_per_launch" in pj:
-                traffic, traffic_src = float(pj["hbm_traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
-                break
-        except Exception:
-            pass
+    # fabric traffic and limiter of the same launch from the committed rocprofv3 PMC summary (separate passes; see
+    # scripts/profile_workload.sh + scripts/summarize_profile.py). Dropped when the kernels changed since.
+    pj, traffic_src, fresh = (None, None, False) if DRY else load_pmc_summary(args.workload)
+    traffic = float(pj["hbm_traffic_bytes_per_launch"]) if (pj and fresh and args.bvh == "device") else None
+    limiter = limiter_from_pmc(pj) if (pj and fresh) else {}
 
     total_rays = n * world * args.steps
     mrays = total_rays / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    kernel_name = ("rtk_trace_packet_kernel<false>" if packet_kernel else "rtk_trace_kernel<%d, false, false>" % (1 if shadow else 0))
     out = {
         "metric": metric,
         "value": round(mrays, 2),
@@ -311,17 +371,35 @@ def main():
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src if traffic else None,
+                     "traffic_unit": ("bytes per launch crossing the L2 -> fabric boundary, Infinity-Cache (MALL) hits INCLUDED: "
+                                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes, %s; not a pure HBM figure for a "
+                                      "131 MB BVH that fits the 256 MiB Infinity Cache" % traffic_src) if traffic else
+                                     ("none: %s was measured on other kernel sources" % traffic_src if pj else None),
+                     "unit_of_work": unit,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "kernel": ("rtk_trace_packet_kernel<false>" if (args.workload == "coherent" and not args.no_tiling and not args.no_packet)
-                                else "rtk_trace_kernel<%d,false>" % (1 if shadow else 0)), "kernel_ms": round(k_ms, 4),
-                     "algorithmic_bytes_per_ray": round(alg_bytes / n, 1),
+                     "kernel": kernel_name, "kernel_ms": round(k_ms, 4),
+                     "limiter": dict(limiter, note="issue-bound, not bandwidth-bound: VALU pipes busy this share of the launch at this "
+                                     "lane utilisation (%s, %.1f GHz assumed); the BVH is served by L2/MALL" % (traffic_src, CLOCK_GHZ)) if limiter else None,
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
                                         "triangles": round(ctr["triangles"] / n, 2)},
                      "wave_steps_per_64_rays": {"nodes": round(ctr["wave_node_steps"] * 64.0 / n, 1),
                                                 "triangles": round(ctr["wave_triangle_steps"] * 64.0 / n, 1)},
+                     "per_ray_model": {"bytes_per_ray": round(per_ray_bytes / n, 1), "gb_s": round(per_ray_bytes / (k_ms * 1e-3) / 1e9, 1),
+                                       "note": "every lane's visit priced at full size; caches absorb these for coherent rays, so this is "
+                                               "cache bandwidth demand, not a fraction of the HBM roofline"},
                      "kernel_mrays_s": round(n / (k_ms * 1e-3) / 1e6, 1)},
     }
+    if args.bvh == "device" and build_ms_device_mesh:
+        # SURVEY.md section 8d, build formula with this build's sizes: 36 B positions in, 12 B (key, index) out,
+        # P sort passes x 24 B (12-B pair read + written), 2 x 32 B binary node (refit write, collapse read),
+        # 128 B x wide nodes per triangle + 48 B triangle record out
+        passes = 6 if cfg["num_tris"] < (1 << 24) else 8
+        bpt = 36 + 12 + passes * 24 + 64 + 128.0 * info["num_nodes"] / cfg["num_tris"] + 48
+        gbs = cfg["num_tris"] * bpt / (build_ms_device_mesh * 1e-3) / 1e9
+        out["build"] = {"triangles": cfg["num_tris"], "ms": round(build_ms_device_mesh, 3), "what": "rtk_dev_scene_build, mesh resident in HBM, "
+                        "wall time inside the library (all kernels, no PCIe)", "sort_passes": passes,
+                        "algorithmic_bytes_per_triangle": round(bpt, 1), "achieved_gb_s": round(gbs, 1),
+                        "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "mtris_s": round(cfg["num_tris"] / build_ms_device_mesh / 1e3, 1)}
 
     # ---- CPU baseline: the oracle (a port of rtk.c's trace path) on this host's cores -----
     if not args.no_cpu_baseline:
@@ -362,8 +440,15 @@ def main():
             t_at = float(oh["t"][same][int(relv.argmax())]) if same.any() else 0.0   # large only where t itself is ~0 (cancellation)
             exact = float(np.mean((g["t"][same] == oh["t"][same]) & (g["u"][same] == oh["u"][same]) &
                                   (g["v"][same] == oh["v"][same]))) if same.any() else 1.0
-            return {"rays": sample, "ids_exact": mism == 0, "id_mismatches": mism, "max_rel_t": rel, "t_at_max_rel_t": t_at,
-                    "tuv_bit_exact_fraction": exact}
+            # every ray on which the two disagree about WHICH triangle, with both candidates' t: these are near ties
+            # (two triangles within an ulp in t) that rtk.c's group-of-four double-precision rule (rtk.c:302-336)
+            # resolves by leaf grouping; tests/golden/near_ties.npz holds the reference's values for both groupings
+            bad = np.nonzero((gm != om) | (both & (g["prim"] != oh["triangle_index"])))[0]
+            listing = [{"ray": int(sel[i]), "gpu_prim": int(g["prim"][i]), "gpu_t": float(g["t"][i]),
+                        "cpu_prim": int(oh["triangle_index"][i]) if om[i] else None, "cpu_t": float(oh["t"][i]) if om[i] else None,
+                        "t_ulps_apart": f32_ulps(g["t"][i], oh["t"][i]) if (gm[i] and om[i]) else None} for i in bad[:64]]
+            return {"rays": sample, "ids_exact": mism == 0, "id_mismatches": mism, "mismatching_rays": listing, "max_rel_t": rel,
+                    "t_at_max_rel_t": t_at, "tuv_bit_exact_fraction": exact}
 
         base = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": "%d rays = every %d-th ray of the same batch, closest-hit on the oracle's SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"

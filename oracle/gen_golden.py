@@ -193,6 +193,96 @@ def gen_edge():
          **compact(hits, mask))
 
 
+def _f32_ulps(a, b):
+    """Distance in units in the last place between positive float32 arrays."""
+    return np.abs(a.astype(np.float32).view(np.int32).astype(np.int64) - b.astype(np.float32).view(np.int32).astype(np.int64))
+
+
+def find_near_ties(blob, make_rays, total, ulps, chunk=1 << 21, max_cand=4):
+    """Rays of a batch whose two closest candidates lie within `ulps` float32 ulps of each other in t.
+    Returns (ray_index[k], cand_prim[k, max_cand]) with 0xffffffff padding. Uses the CPU restatement's own
+    SAH tree: the candidates' t values can move by an ulp with the leaf grouping (rtk.c:302-336), so the
+    threshold is several ulps wide."""
+    out_idx, out_cand = [], []
+    for a in range(0, total, chunk):
+        n = min(chunk, total - a)
+        rays = make_rays(a, n)
+        h1, m1 = po.trace(blob, rays)
+        t1 = np.where(m1, h1["t"], 0).astype(np.float32)
+        mesh1 = np.where(m1, h1["mesh_index"], 0xFFFFFFFF).astype(np.uint32)
+        h2, m2 = po.trace_filtered(blob, rays, after=(t1, mesh1, h1["triangle_index"]))
+        both = m1 & m2
+        near = both & (_f32_ulps(np.where(both, h2["t"], 1), np.where(both, h1["t"], 1)) <= ulps)
+        sel = np.nonzero(near)[0]
+        if sel.size == 0:
+            continue
+        cand = np.full((sel.size, max_cand), 0xFFFFFFFF, np.uint32)
+        cand[:, 0] = h1["triangle_index"][sel]
+        cand[:, 1] = h2["triangle_index"][sel]
+        cur_t, cur_tri, sub, alive = h2["t"][sel].copy(), h2["triangle_index"][sel].copy(), rays[sel], np.ones(sel.size, bool)
+        for k in range(2, max_cand):
+            hk, mk = po.trace_filtered(blob, sub, after=(cur_t, np.where(alive, 0, 0xFFFFFFFF).astype(np.uint32), cur_tri))
+            alive = alive & mk & (_f32_ulps(np.where(mk, hk["t"], 1), h1["t"][sel]) <= ulps)
+            cand[alive, k] = hk["triangle_index"][alive]
+            cur_t = np.where(alive, hk["t"], cur_t).astype(np.float32)
+            cur_tri = np.where(alive, hk["triangle_index"], cur_tri).astype(np.uint32)
+        out_idx.append(sel.astype(np.int64) + a)
+        out_cand.append(cand)
+        print("    rays %d..%d: %d near ties" % (a, a + n, sel.size), flush=True)
+    if not out_idx:
+        return np.zeros(0, np.int64), np.zeros((0, max_cand), np.uint32)
+    return np.concatenate(out_idx), np.concatenate(out_cand)
+
+
+def reference_values_both_groupings(tris, rays, cand):
+    """For every (ray, candidate triangle X): what the REAL rtk_trace_ray returns for X under the two groupings
+    a leaf can put it in -- alone with three padding slots (rtk.c:306: the whole group takes the double-precision
+    edge functions) and in a full group of four (here four copies of X: the float path unless X itself has an
+    exactly-zero edge function). Returns hit[k, c, 2] and tuv[k, c, 2, 3]; index 0 = padded group, 1 = full group."""
+    k, mc = cand.shape
+    hit = np.zeros((k, mc, 2), np.uint8)
+    tuv = np.zeros((k, mc, 2, 3), np.float32)
+    tv = tris.reshape(-1, 3, 3)
+    for i in range(k):
+        for c in range(mc):
+            p = int(cand[i, c])
+            if p == 0xFFFFFFFF:
+                continue
+            for g, reps in enumerate((1, 4)):
+                blobs = po.leaf_chain_blobs(np.repeat(tv[p:p + 1], reps, axis=0), triangle_index=np.full(reps, p, np.uint32))
+                h, m = po.ref_trace_chain(blobs, rays[i:i + 1], threads=1)
+                hit[i, c, g] = m[0]
+                if m[0]:
+                    assert h["triangle_index"][0] == p
+                    tuv[i, c, g] = (h["t"][0], h["u"][0], h["v"][0])
+    return hit, tuv
+
+
+def gen_near_ties(tris, ulps=8):
+    """tests/golden/near_ties.npz: every ray of the FULL config-2 and config-3 batches (2^24 rays each) whose two
+    closest candidates are within `ulps` ulps in t, with the reference's own values for each candidate under both
+    leaf groupings. Which of two such candidates rtk.c reports depends on its leaf grouping (DESIGN.md section 4);
+    the GPU test checks that whatever the device BVH reports for these rays is one of the reference's answers."""
+    t0 = time.time()
+    blob = po.build_scene([dict(positions=tris)])
+    print("  oracle SAH scene built in %.1f s" % (time.time() - t0))
+    total = 4096 * 4096
+    out = {}
+    for name, make in (("cfg2", lambda a, n: synth.rays_pinhole(4096, 4096, first=a, count=n)),
+                       ("cfg3", lambda a, n: synth.rays_incoherent(n, first=a))):
+        t0 = time.time()
+        idx, cand = find_near_ties(blob, make, total, ulps)
+        rays = np.concatenate([make(int(i), 1) for i in idx]) if len(idx) else np.zeros(0, RAY_DTYPE)
+        hit, tuv = reference_values_both_groupings(tris, rays, cand)
+        print("  %s: %d near-tie rays of %d (%.0f s)" % (name, len(idx), total, time.time() - t0))
+        out[name + "_ray_index"] = idx
+        out[name + "_rays"] = rays.view(np.float32).reshape(-1, 8)
+        out[name + "_cand_prim"] = cand
+        out[name + "_cand_hit"] = hit
+        out[name + "_cand_tuv"] = tuv
+    save("near_ties.npz", scene_sha256=sha(tris), ulps=np.int64(ulps), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="edge,cfg1,cfg2,cfg3,cfg5")
@@ -208,8 +298,10 @@ def main():
         gen_edge()
     if "cfg1" in only:
         gen_cfg1()
-    if only & {"cfg2", "cfg3"}:
+    if only & {"cfg2", "cfg3", "near_ties"}:
         tris = synth.scene_for_config(2)
+        if "near_ties" in only:
+            gen_near_ties(tris)
         if "cfg2" in only:
             gen_cfg2(tris)
         if "cfg3" in only:

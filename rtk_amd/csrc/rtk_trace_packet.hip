@@ -232,16 +232,15 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 // Push one child: its reference into the wave-uniform stack register, every lane's own entry distance into
 // LDS (or the spill area). A push that does not fit (impossible for a tree: the launcher refuses scenes
 // needing more than PK_WAVE_STACK entries and sizes the spill area from the depth) is dropped without
-// advancing sp, and flagged.
+// advancing sp and remembered in a wave-uniform flag that is reported once per tile.
 #define PK_PUSH(dist_, ref_)                                                                                      \
 	do {                                                                                                          \
-		const bool in_lds_ = sp < PK_LDS_STACK;                                                                   \
-		if (sp < PK_WAVE_STACK && (in_lds_ || sp - PK_LDS_STACK < p.spill_cap)) {                                 \
-			if (in_lds_) lds_t[sp][lane] = (dist_);                                                               \
+		if (sp < PK_LDS_STACK + p.spill_cap) {                                                                    \
+			if (sp < PK_LDS_STACK) lds_t[sp][lane] = (dist_);                                                     \
 			else { spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane] = (dist_); if (COUNT) c_spills++; } \
 			stack = stack_write(stack, (ref_), sp, lane);                                                         \
 			sp++;                                                                                                 \
-		} else if (lane == 0) p.counter[RTK_ERROR_WORD] = 1ull;                                                   \
+		} else overflow = true;                                                                                   \
 	} while (0)
 
 template <bool COUNT>
@@ -329,6 +328,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 		uint32_t sp = 0;             // wave-uniform
 		uint32_t top = 0;            // wave-uniform: root
 		bool live = alive;           // per lane
+		bool overflow = false;       // wave-uniform: a push did not fit (corrupted scene)
 
 		for (;;) {
 			bool pop = false;
@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			}
 		}
 
+		if (overflow && lane == 0) p.counter[RTK_ERROR_WORD] = 1ull;
 		if (alive) {
 			*reinterpret_cast<float4 *>(p.hits + ray_index) = make_float4(L.t, L.u, L.v, __uint_as_float(L.prim));
 			if (COUNT) {

@@ -23,6 +23,13 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     out = {"kernel": KERNEL, "source": src}
+    # identity of the traversal kernels this was measured on (bench.py drops the traffic figure when they change)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h", "rtk_amd/csrc/rtk_dev.h"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    out["kernel_source_sha16"] = h.hexdigest()[:16]
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))

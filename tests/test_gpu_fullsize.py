@@ -67,3 +67,61 @@ def test_incoherent_full_batch(api, scene):
     nhit = _check_geometry(tris, rays, rec)
     assert nhit / N > 0.99
     assert ds.trace(rays, opts=api.make_opts(static=True, node_exit=1), full=False).tobytes() == rec.tobytes()
+
+
+def _check_near_ties(g, cfg, rec, what):
+    """rec: the device's records for the fixture's near-tie rays of `cfg`. What the device reports must be one of the
+    REAL reference's answers: the reported triangle X is one of the ray's near-tie candidates, its (t, u, v) are
+    bit-for-bit what rtk.c computes for X under one of the two groupings a leaf can put it in (padded group: double
+    precision edge functions, rtk.c:306; full group: float), and no other candidate Y beats it under BOTH of Y's
+    groupings (otherwise no leaf grouping could make rtk.c report X)."""
+    cand, hit, tuv = g[cfg + "_cand_prim"], g[cfg + "_cand_hit"], g[cfg + "_cand_tuv"]
+    assert len(rec) == len(cand) and len(cand) > 50
+    picked_second = 0
+    for i in range(len(rec)):
+        x = int(rec["prim"][i])
+        cs = [int(c) for c in cand[i] if c != 0xFFFFFFFF]
+        assert x in cs, "%s ray %d: device reports %d, not a near-tie candidate %s" % (what, i, x, cs)
+        k = cs.index(x)
+        mine = (float(rec["t"][i]), float(rec["u"][i]), float(rec["v"][i]))
+        versions = [tuple(float(v) for v in tuv[i, k, grp]) for grp in (0, 1) if hit[i, k, grp]]
+        assert mine in versions, "%s ray %d prim %d: (t,u,v) %s is none of the reference's %s" % (what, i, x, mine, versions)
+        for j, y in enumerate(cs):
+            if j == k:
+                continue
+            beats = [bool(hit[i, j, grp]) and ((float(tuv[i, j, grp, 0]), y) < (mine[0], x)) for grp in (0, 1)]
+            assert not all(beats), "%s ray %d: candidate %d beats the reported %d under every grouping" % (what, i, y, x)
+        picked_second += k != 0
+    return picked_second
+
+
+def test_near_tie_rays_are_reference_answers(api, oracle, scene, golden_dir):
+    """Full-batch id parity: on all 2^24 rays of config 2 and of config 3 there are 384 + 123 rays whose two closest
+    candidates lie within 8 ulps in t (tests/golden/near_ties.npz, found on the CPU and evaluated with the REAL
+    rtk.c under both leaf groupings by oracle/gen_golden.py). Which one rtk.c reports depends on its leaf grouping
+    (rtk.c:302-336), so two valid BVHs may disagree on them -- these are the id mismatches bench.py lists between
+    the device BVH and the CPU oracle's own SAH tree. Here: (a) on these rays the device is bit-identical to the
+    oracle traversing the SAME leaves (the grouping rule is implemented exactly), both kernels; (b) every device
+    answer is one of the real reference's answers for that triangle and is not beaten under every grouping."""
+    from rtk_amd.types import RAY_DTYPE
+    from tests.util import load_golden, sha
+    tris, ds = scene
+    g = load_golden(golden_dir, "near_ties.npz")
+    assert sha(tris) == str(g["scene_sha256"])
+    blob = oracle.Blob(ds.export_blob())
+    seconds = 0
+    for cfg in ("cfg2", "cfg3"):
+        rays = np.ascontiguousarray(g[cfg + "_rays"]).view(RAY_DTYPE).reshape(-1)
+        rec = ds.trace(rays, full=False)
+        oh, om = oracle.trace(blob, rays)
+        assert om.all() and (rec["prim"] == oh["triangle_index"]).all()
+        assert (rec["t"] == oh["t"]).all() and (rec["u"] == oh["u"]).all() and (rec["v"] == oh["v"]).all()
+        seconds += _check_near_ties(g, cfg, rec, cfg + " per-lane")
+    # config 2 through the packet kernel as well: the whole frame, then the fixture's rays out of it
+    frame = synth.rays_pinhole(4096, 4096)
+    full = ds.trace(frame, opts=api.make_opts(image=(4096, 4096)), full=False)
+    idx = g["cfg2_ray_index"]
+    assert frame[idx].tobytes() == np.ascontiguousarray(g["cfg2_rays"]).tobytes()
+    _check_near_ties(g, "cfg2", full[idx], "cfg2 packet")
+    # the fixture is not vacuous: the device BVH does resolve some of these ties the other way than the CPU's SAH tree
+    assert seconds >= 1
