@@ -84,6 +84,8 @@ typedef struct rtk_trace_opts {
 } rtk_trace_opts;
 #define RTK_TRACE_STATIC    1u   /* one fixed ray per lane, no persistent refill (A/B only) */
 #define RTK_TRACE_NO_PACKET 2u   /* image-shaped batch, but use the per-lane kernel (A/B only) */
+#define RTK_TRACE_POSTPONE    8u  /* per-lane kernel: park a leaf and keep descending (speculative; same results) */
+#define RTK_TRACE_NO_POSTPONE 16u /* ... or not; neither flag = the library default */
 #define RTK_TRACE_SORT_RAYS 4u   /* reorder the batch by (origin cell, direction octant) before tracing; hits
                                     still land in input order. Pays off for large incoherent batches. */
 

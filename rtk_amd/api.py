@@ -15,11 +15,13 @@ import numpy as np
 from .types import (HIT_DTYPE, HIT_RECORD_DTYPE, RAY_DTYPE, MeshSet, SceneDesc, SceneHeader)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtk_amd.so")
+LIB_PATH = os.environ.get("RTK_AMD_LIB") or os.path.join(HERE, "librtk_amd.so")   # RTK_AMD_LIB: kernel A/B builds only
 
 RTK_TRACE_STATIC = 1
 RTK_TRACE_NO_PACKET = 2
 RTK_TRACE_SORT_RAYS = 4
+RTK_TRACE_POSTPONE = 8
+RTK_TRACE_NO_POSTPONE = 16
 
 
 class RtkError(RuntimeError):
@@ -180,10 +182,12 @@ def to_device(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False):
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, postpone=None):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
+    if postpone is not None:
+        o.flags |= RTK_TRACE_POSTPONE if postpone else RTK_TRACE_NO_POSTPONE
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

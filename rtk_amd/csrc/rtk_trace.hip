@@ -80,8 +80,35 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 		} else p.counter[RTK_ERROR_WORD] = 1ull;                                                            \
 	} while (0)
 
-template <int MODE /*0 closest, 1 any*/, bool COUNT, bool FILT /*built-in candidate filters*/>
-__global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
+// Next node from the stack, skipping entries that start behind the current hit (rtk.c:432; canonical ties: an
+// entry AT the hit distance may still hold an equal-t candidate with a lower id). top = NONE when it is empty.
+#define RTK_POP()                                                                                           \
+	do {                                                                                                    \
+		top = RTK_REF_NONE;                                                                                 \
+		while (sp > 0u) {                                                                                   \
+			--sp;                                                                                           \
+			const uint2 e_ = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane]; \
+			if (__uint_as_float(e_.x) > best_t) continue;                                                   \
+			top = e_.y; top_t = __uint_as_float(e_.x);                                                      \
+			break;                                                                                          \
+		}                                                                                                   \
+	} while (0)
+
+// POSTPONE: a lane that arrives at a leaf parks it in `pend` and keeps descending from the stack, so that it
+// stays in the node loop with the other lanes; the parked leaf is tested in the next leaf phase. What is
+// visited meanwhile may turn out to lie behind the hit the parked leaf produces (speculation), never the
+// other way round, so results do not change.
+#define RTK_PARK_LEAF()                                                                                     \
+	do {                                                                                                    \
+		if (POSTPONE && pend == RTK_REF_NONE && top != RTK_REF_NONE && (int32_t)top < 0) { pend = top; RTK_POP(); } \
+	} while (0)
+
+#ifndef PL_MIN_WAVES
+#define PL_MIN_WAVES 4             // waves per SIMD the register allocator must leave room for
+#endif
+
+template <int MODE /*0 closest, 1 any*/, bool COUNT, bool FILT /*built-in candidate filters*/, bool POSTPONE /*speculative descent past one leaf*/>
+__global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(TraceParams p)
 {
 	__shared__ uint2 s_stack[WAVES_PER_BLOCK][LDS_STACK][64];
 
@@ -108,11 +135,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 
 	// per-lane ray state
 	bool active = false;
-	unsigned long long ray_index = 0;
+	uint32_t ray_index = 0;               // the launcher keeps batches below 2^32 rays
 	float ox = 0, oy = 0, oz = 0, rdx = 0, rdy = 0, rdz = 0, tmin_ray = 0, tmax_ray = 0;
 	float sox = 0, soy = 0, soz = 0, shx = 0, shy = 0, shz = 0;
 	bool kz0 = false, kz1 = false;
-	uint32_t onx = 0, ofx = 0, ony = 0, ofy = 0, onz = 0, ofz = 0;
+	uint32_t onx = 0, ony = 0, onz = 0;     // byte offset of the NEAR plane row of each axis inside a node; far = the other row
+	uint32_t pend = RTK_REF_NONE;           // POSTPONE: a leaf whose triangles are still to be tested
+	float top_t = 0.0f;                     // entry distance of `top` (POSTPONE: lets a hit found meanwhile cull it)
 	float best_t = 0, best_u = 0, best_v = 0;
 	uint32_t best_prim = RTK_PRIM_NONE;
 	float after_t = 0;                                    // FILT: candidates must come after (after_t, after_prim)
@@ -161,7 +190,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					__builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
 				if (!active && rank < take) {
-					ray_index = p.perm ? (unsigned long long)p.perm[w_next + rank] : map_index(w_next + rank, p.image_w, p.image_h);
+					ray_index = p.perm ? p.perm[w_next + rank] : (uint32_t)map_index(w_next + rank, p.image_w, p.image_h);
 					const float4 r0 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index));
 					const float4 r1 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
 					ox = r0.x; oy = r0.y; oz = r0.z;
@@ -186,9 +215,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
 					// near/far plane offsets inside the node by direction sign BIT (rtk.c:152-154, 458-463)
 					const uint32_t sx = __float_as_uint(dx) >> 31, sy = __float_as_uint(dy) >> 31, sz = __float_as_uint(dz) >> 31;
-					onx = sx * 16u;        ofx = 16u - onx;
-					ony = 32u + sy * 16u;  ofy = 80u - ony;
-					onz = 64u + sz * 16u;  ofz = 144u - onz;
+					onx = sx * 16u;
+					ony = 32u + sy * 16u;
+					onz = 64u + sz * 16u;
 					special = !(isfinite(rdx) && isfinite(rdy) && isfinite(rdz) && rdx != 0.0f && rdy != 0.0f && rdz != 0.0f &&
 						isfinite(ox) && isfinite(oy) && isfinite(oz) && tmin_ray == tmin_ray && tmax_ray == tmax_ray);
 					best_t = tmax_ray; best_u = 0.0f; best_v = 0.0f; best_prim = RTK_PRIM_NONE;
@@ -199,6 +228,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					}
 					top = 0u;  // root node
 					sp = 0u;
+					pend = RTK_REF_NONE;
 					active = true;
 				}
 				w_next += take;
@@ -217,13 +247,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			const bool want_node = active && (int32_t)top >= 0;
 			const unsigned long long m_node = __ballot(want_node);
 			if (m_node == 0ull) break;
-			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
+			const bool leaf_waits = POSTPONE ? (active && pend != RTK_REF_NONE) : (active && top != RTK_REF_NONE && (int32_t)top < 0);
+			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(leaf_waits) != 0ull) break;
 			if (COUNT) w_node_steps++;
 			if (!want_node) continue;
 			const uint32_t a_node = top << 7;
 			f32x4 nx, fx, ny, fy, nz, fz;
 			u32x4 ch;
-			load_node(nodes, a_node + onx, a_node + ofx, a_node + ony, a_node + ofy, a_node + onz, a_node + ofz, a_node,
+			load_node(nodes, a_node + onx, (a_node + 16u) - onx, a_node + ony, (a_node + 80u) - ony, a_node + onz, (a_node + 144u) - onz, a_node,
 				nx, fx, ny, fy, nz, fz, ch);
 			if (COUNT) c_nodes++;
 			uint32_t ref[4] = { ch.x, ch.y, ch.z, ch.w };
@@ -264,17 +295,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			cswap(key[1], ref[1], key[3], ref[3]);
 			cswap(key[1], ref[1], key[2], ref[2]);
 			if (nhit == 0u) {
-				// pop, skipping entries that start behind the current hit (rtk.c:432)
-				top = RTK_REF_NONE;
-				while (sp > 0u) {
-					--sp;
-					const uint2 e = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane];
-					if (__uint_as_float(e.x) > best_t) continue;
-					top = e.y;
-					break;
-				}
+				RTK_POP();
 			} else {
 				top = ref[0];
+				top_t = key[0];
 #pragma unroll
 				for (int i = 3; i >= 1; i--) {
 					if (nhit > (uint32_t)i) {
@@ -283,6 +307,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 					}
 				}
 			}
+			RTK_PARK_LEAF();
 		}
 
 		// ---------------------------------------------------------------- leaf
@@ -293,8 +318,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 		// known up front; a zero inside a full group is rare, so the group is simply
 		// redone from a snapshot of the best hit. This keeps t/u/v bit-identical to
 		// rtk.c traversing the same leaves.
-		if (active && top != RTK_REF_NONE && (int32_t)top < 0) {
-			const uint32_t slot0 = top & 0x7fffffffu;
+		const uint32_t leaf_ref = POSTPONE ? pend : top;
+		if (active && leaf_ref != RTK_REF_NONE && (int32_t)leaf_ref < 0) {
+			const uint32_t slot0 = leaf_ref & 0x7fffffffu;
 			if (COUNT) c_leaves++;
 			uint32_t i = 0, n = 1;
 			bool force = false, redo = false;
@@ -381,21 +407,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS) rtk_trace_kernel(TraceParams p)
 			}
 			if (MODE == 1 && best_prim != RTK_PRIM_NONE) {
 				top = RTK_REF_NONE;
+				pend = RTK_REF_NONE;
 				sp = 0u;
+			} else if (POSTPONE) {
+				pend = RTK_REF_NONE;
+				// what was popped before this leaf was tested may now start behind the hit
+				if (top != RTK_REF_NONE && top_t > best_t) RTK_POP();
+				RTK_PARK_LEAF();
 			} else {
-				top = RTK_REF_NONE;
-				while (sp > 0u) {
-					--sp;
-					const uint2 e = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane];
-					if (__uint_as_float(e.x) > best_t) continue;
-					top = e.y;
-					break;
-				}
+				RTK_POP();
 			}
 		}
 
 		// ---------------------------------------------------------------- retire
-		if (active && top == RTK_REF_NONE) {
+		if (active && top == RTK_REF_NONE && (!POSTPONE || pend == RTK_REF_NONE)) {
 			if (MODE == 1) {
 				p.occluded[ray_index] = best_prim != RTK_PRIM_NONE ? 1 : 0;
 			} else {
@@ -513,33 +538,42 @@ namespace {
 
 typedef void (*trace_kernel_fn)(TraceParams);
 
-// variant index: any_hit | counted << 1 | filtered << 2
+// variant index: any_hit | counted << 1 | filtered << 2 | postpone << 3
 trace_kernel_fn trace_variant(int v)
 {
 	switch (v) {
-	case 0: return rtk_trace_kernel<0, false, false>;
-	case 1: return rtk_trace_kernel<1, false, false>;
-	case 2: return rtk_trace_kernel<0, true, false>;
-	case 3: return rtk_trace_kernel<1, true, false>;
-	case 4: return rtk_trace_kernel<0, false, true>;
-	case 5: return rtk_trace_kernel<1, false, true>;
-	case 6: return rtk_trace_kernel<0, true, true>;
-	default: return rtk_trace_kernel<1, true, true>;
+	case 0: return rtk_trace_kernel<0, false, false, false>;
+	case 1: return rtk_trace_kernel<1, false, false, false>;
+	case 2: return rtk_trace_kernel<0, true, false, false>;
+	case 3: return rtk_trace_kernel<1, true, false, false>;
+	case 4: return rtk_trace_kernel<0, false, true, false>;
+	case 5: return rtk_trace_kernel<1, false, true, false>;
+	case 6: return rtk_trace_kernel<0, true, true, false>;
+	case 7: return rtk_trace_kernel<1, true, true, false>;
+	case 8: return rtk_trace_kernel<0, false, false, true>;
+	case 9: return rtk_trace_kernel<1, false, false, true>;
+	case 10: return rtk_trace_kernel<0, true, false, true>;
+	case 11: return rtk_trace_kernel<1, true, false, true>;
+	case 12: return rtk_trace_kernel<0, false, true, true>;
+	case 13: return rtk_trace_kernel<1, false, true, true>;
+	case 14: return rtk_trace_kernel<0, true, true, true>;
+	default: return rtk_trace_kernel<1, true, true, true>;
 	}
 }
+enum { VARIANT_PACKET = 16, VARIANT_PACKET_COUNTED = 17, NUM_VARIANTS = 18 };
 
 // resident workgroups per CU of each kernel variant, per device; filled on first use
 std::mutex g_occ_mutex;
-int g_occ[RTK_MAX_DEVICES][10];
+int g_occ[RTK_MAX_DEVICES][NUM_VARIANTS];
 
-int blocks_per_cu_of(int device, int variant /*0..7 per-lane, 8/9 packet plain/counted*/)
+int blocks_per_cu_of(int device, int variant)
 {
 	std::lock_guard<std::mutex> lock(g_occ_mutex);
 	if (device < 0 || device >= RTK_MAX_DEVICES) device = 0;
 	int &o = g_occ[device][variant];
 	if (o == 0) {
 		int nb = 0;
-		if (variant >= 8) nb = rtk_packet_occupancy(variant == 9);
+		if (variant >= VARIANT_PACKET) nb = rtk_packet_occupancy(variant == VARIANT_PACKET_COUNTED);
 		else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_variant(variant), BLOCK_THREADS, 0) != hipSuccess) nb = 0;
 		o = nb >= 1 ? nb : 1;
 	}
@@ -625,7 +659,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 
 	// image-shaped closest-hit batches go to the wave-packet kernel (rtk_trace_packet.hip)
 	const bool packet = !any_hit && !filtered && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
-	const int variant = packet ? (counted ? 9 : 8) : ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0));
+	static const int postpone_default = getenv("RTK_AMD_POSTPONE") ? atoi(getenv("RTK_AMD_POSTPONE")) : 0;
+	const bool postpone = opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_POSTPONE | RTK_TRACE_NO_POSTPONE))
+		? (opts->flags & RTK_TRACE_POSTPONE) != 0 : postpone_default != 0;
+	const int variant = packet ? (counted ? VARIANT_PACKET_COUNTED : VARIANT_PACKET)
+		: ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0) | (postpone ? 8 : 0));
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
 
