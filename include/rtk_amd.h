@@ -84,8 +84,7 @@ typedef struct rtk_trace_opts {
 } rtk_trace_opts;
 #define RTK_TRACE_STATIC    1u   /* one fixed ray per lane, no persistent refill (A/B only) */
 #define RTK_TRACE_NO_PACKET 2u   /* image-shaped batch, but use the per-lane kernel (A/B only) */
-#define RTK_TRACE_POSTPONE    8u  /* per-lane kernel: park a leaf and keep descending (speculative; same results) */
-#define RTK_TRACE_NO_POSTPONE 16u /* ... or not; neither flag = the library default */
+#define RTK_TRACE_EXACT_NODES 8u  /* per-lane kernels: read the 128 B exact nodes instead of the 64 B compressed ones (A/B only) */
 #define RTK_TRACE_SORT_RAYS 4u   /* reorder the batch by (origin cell, direction octant) before tracing; hits
                                     still land in input order. Pays off for large incoherent batches. */
 
@@ -136,6 +135,7 @@ typedef struct rtk_dev_scene_check {
 	uint64_t triangles_missing, triangles_duplicated;
 	uint64_t nodes_unreachable, nodes_shared;
 	uint64_t primitive_id_errors;   /* id out of range, repeated, or prim -> slot table inconsistent */
+	uint64_t compressed_node_errors; /* a 64 B compressed node whose decoded child box does not contain the exact one */
 	uint64_t first_bad_index;       /* smallest node / slot index that raised an error, ~0 if none */
 	uint64_t content_hash;
 } rtk_dev_scene_check;
@@ -188,6 +188,27 @@ int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, s
 
 int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, rtk_trace_counters *out);
+
+/* -- several GPUs of one node, one process --
+ * Rays shard, nothing else: the scene is replicated (the deterministic build or the upload runs on every GPU),
+ * shard r of R owns the contiguous range rtk_amd_shard_range(n, r, R) of the batch, and the only exchange is the
+ * gather of the 16-byte records, each GPU copying straight to the final place on its own stream (its own xGMI
+ * link into the root), piece by piece while the rest of its shard is still being traced. Synchronous calls. */
+typedef struct rtk_mgpu rtk_mgpu;
+void rtk_amd_shard_range(size_t n, int rank, int num_shards, size_t *first, size_t *count);
+rtk_mgpu *rtk_mgpu_create(const int *devices, int num_devices);   /* NULL / 0: all devices; an id may repeat (virtual shards) */
+void rtk_mgpu_destroy(rtk_mgpu *m);
+int rtk_mgpu_num_devices(const rtk_mgpu *m);
+const rtk_dev_scene *rtk_mgpu_scene(const rtk_mgpu *m, int index);
+int rtk_mgpu_build(rtk_mgpu *m, const rtk_scene_desc *desc);      /* rtk_dev_scene_build on every GPU */
+int rtk_mgpu_upload(rtk_mgpu *m, const rtk_scene *scene);         /* rtk_dev_scene_upload on every GPU */
+/* host rays in, host records out (records[i] belongs to rays[i]) */
+int rtk_mgpu_trace_rays(rtk_mgpu *m, const rtk_ray *rays, size_t n, rtk_hit_record *records, const rtk_trace_opts *opts);
+/* device-resident shards: d_rays[r] / d_records[r] (counts[r] elements) live on GPU r of the context; if d_gathered
+ * is not NULL it is memory of GPU `root_index` that receives all records, shard after shard. opts applies per shard
+ * (an image-shaped shard is traced in bands of whole tile rows by the packet kernel). */
+int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_rays, const size_t *counts, rtk_hit_record *const *d_records,
+	rtk_hit_record *d_gathered, int root_index, const rtk_trace_opts *opts);
 
 /* -- host-pointer convenience (PCIe-inclusive, synchronous) --
  * Closest hits of n rays against a scene blob. hits[i] is written where the ray hit

@@ -20,8 +20,7 @@ LIB_PATH = os.environ.get("RTK_AMD_LIB") or os.path.join(HERE, "librtk_amd.so") 
 RTK_TRACE_STATIC = 1
 RTK_TRACE_NO_PACKET = 2
 RTK_TRACE_SORT_RAYS = 4
-RTK_TRACE_POSTPONE = 8
-RTK_TRACE_NO_POSTPONE = 16
+RTK_TRACE_EXACT_NODES = 8
 
 
 class RtkError(RuntimeError):
@@ -41,7 +40,7 @@ class SceneCheck(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "nodes_checked", "leaves_checked", "triangles_checked", "box_violations", "loose_boxes", "bad_references",
         "leaf_format_errors", "triangles_missing", "triangles_duplicated", "nodes_unreachable", "nodes_shared",
-        "primitive_id_errors", "first_bad_index", "content_hash")]
+        "primitive_id_errors", "compressed_node_errors", "first_bad_index", "content_hash")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -80,7 +79,8 @@ RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_
                      "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_trace_rays", "rtk_amd_forget_scene",
                      "rtk_dev_scene_validate", "rtk_amd_release_workspace", "rtk_dev_scene_upload_buffer",
                      "rtk_dev_trace_rays_filtered", "rtk_dev_trace_rays_any_filtered", "rtk_dev_trace_status",
-                     "rtk_trace_rays_filter"]
+                     "rtk_trace_rays_filter", "rtk_amd_shard_range", "rtk_mgpu_create", "rtk_mgpu_destroy", "rtk_mgpu_num_devices",
+                     "rtk_mgpu_scene", "rtk_mgpu_build", "rtk_mgpu_upload", "rtk_mgpu_trace_rays", "rtk_mgpu_trace_rays_device"]
 
 _lib = None
 
@@ -133,6 +133,19 @@ def lib():
     L.rtk_dev_trace_status.argtypes = [C.c_void_p, C.c_void_p]
     L.rtk_trace_rays_filter.restype = C.c_size_t
     L.rtk_trace_rays_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtk_amd_shard_range.restype = None
+    L.rtk_amd_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.rtk_mgpu_create.restype = C.c_void_p
+    L.rtk_mgpu_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.rtk_mgpu_destroy.restype = None
+    L.rtk_mgpu_destroy.argtypes = [C.c_void_p]
+    L.rtk_mgpu_num_devices.argtypes = [C.c_void_p]
+    L.rtk_mgpu_scene.restype = C.c_void_p
+    L.rtk_mgpu_scene.argtypes = [C.c_void_p, C.c_int]
+    L.rtk_mgpu_build.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.rtk_mgpu_upload.argtypes = [C.c_void_p, C.c_void_p]
+    L.rtk_mgpu_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts)]
+    L.rtk_mgpu_trace_rays_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(TraceOpts)]
     L.rtk_trace_ray_filter.restype = C.c_bool
     L.rtk_trace_ray_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rtk_amd_release_workspace.restype = None
@@ -182,12 +195,12 @@ def to_device(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, postpone=None):
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, exact_nodes=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
-    if postpone is not None:
-        o.flags |= RTK_TRACE_POSTPONE if postpone else RTK_TRACE_NO_POSTPONE
+    if exact_nodes:
+        o.flags |= RTK_TRACE_EXACT_NODES
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

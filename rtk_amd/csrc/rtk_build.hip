@@ -1246,9 +1246,11 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
 	if (!d_nodes) return fail("out of device memory");
 	if (hipMemcpyAsync(d_nodes, d_nodes_tmp, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail("copy");
+	ds->view.nodes = d_nodes;
+	ds->view.num_nodes = total_nodes;
+	if (rtk_quantize_nodes(ds, 0) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
 	if (hipStreamSynchronize(0) != hipSuccess) return fail("sync");   // the workspace is handed back below
 
-	ds->view.nodes = d_nodes;
 	ds->view.tris = d_tris;
 	ds->view.vertex_index = d_vertex_index;
 	ds->view.prim_slot = d_prim_slot;

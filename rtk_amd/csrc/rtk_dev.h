@@ -37,6 +37,20 @@ struct DevNode {
 };
 static_assert(sizeof(DevNode) == 128, "node must be one 128 B line");
 
+// Compressed node for the per-lane kernels, 64 B = half a cache line (two children of one parent share a line):
+// child boxes quantised to 8 bits per plane on a per-node, per-axis power-of-two grid anchored at the node's own
+// min corner. Decoded plane = org + q * scale; low planes round down, high planes round up, so a decoded box
+// always CONTAINS the exact one (checked in double precision when it is made, and again by the validator).
+// Incoherent and shadow rays are bound by bytes through the fabric; this halves the bytes of a
+// node visit. Hits do not change: culling only ever gets more conservative, the triangles decide the result.
+struct DevNodeQ {
+	float org[3];
+	float scale[3];           // powers of two
+	uint32_t q[3][2];         // [axis][0 = low planes, 1 = high planes], byte k = child k
+	uint32_t child[4];
+};
+static_assert(sizeof(DevNodeQ) == 64, "quantised node must be half a 128 B line");
+
 struct DevTri {
 	float v0[3]; uint32_t prim;   // global primitive id
 	float v1[3]; uint32_t flags;  // RTK_TRI_LAST
@@ -47,6 +61,7 @@ static_assert(sizeof(DevTri) == 48, "triangle record is 48 B");
 // Everything a kernel needs to know about a scene (passed by value).
 struct DevSceneView {
 	const DevNode *nodes;
+	const DevNodeQ *qnodes;        // same tree, compressed boxes (may be NULL)
 	const DevTri *tris;
 	const uint32_t *vertex_index;  // [3*slot+k] original vertex index (rtk_vertex.index)
 	const uint32_t *prim_slot;     // [prim] -> triangle slot
@@ -111,6 +126,9 @@ struct HostBvh {
 };
 int rtk_blob_to_host_bvh(const rtk_scene *scene, size_t avail, HostBvh *out);
 rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
+
+// -- compressed node array (rtk_quant.hip): fills ds->view.qnodes from ds->view.nodes on `stream` --
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream);
 
 // -- radix sort shared with the builder (rtk_build.hip) --
 size_t rtk_sort_scratch_words(uint32_t n);

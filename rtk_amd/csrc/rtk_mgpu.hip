@@ -1,0 +1,240 @@
+// rtk_mgpu.hip -- several GPUs of one node behind the C ABI, one process.
+//
+// Rays are independent and the BVH is read-only, so the path shards by ray range and nothing else:
+//   * the scene is replicated: the deterministic device build (or the blob upload) runs on every GPU,
+//     which costs no traffic at all and gives byte-identical trees (rtk_dev_scene_validate's hash);
+//   * shard r of R owns the contiguous range rtk_amd_shard_range(n, r, R) of the batch, so the gather
+//     of the results is a concatenation at known offsets;
+//   * the only exchange is that gather. Every GPU's records travel straight to their final place
+//     (the caller's host array, or one root GPU's buffer) on the sender's own copy stream: on the xGMI
+//     mesh each sender has its own link into the root, so nothing is relayed and no ring is formed.
+//     A shard is traced in pieces and each piece's records leave while the next piece is being traced
+//     (a 2^24-ray shard produces 256 MB of records; one link direction carries ~77 GB/s).
+// No collective library is involved: peer copies are all a gather onto one root needs; the per-process
+// torch.distributed/RCCL form of the same partitioning lives in rtk_amd/shard.py for bench.py --gpus N.
+#include "rtk_dev.h"
+
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+const size_t MGPU_PIECE = (size_t)1 << 21;      // rays per piece: 32 MB of records per copy
+
+struct DeviceSlot {
+	int device = 0;
+	rtk_dev_scene *scene = nullptr;
+	hipStream_t trace_stream = nullptr, copy_stream = nullptr;
+	std::vector<hipEvent_t> events;            // one per piece in flight
+	rtk_ray *d_rays = nullptr;                 // staging for host-pointer calls
+	rtk_hit_record *d_rec = nullptr;
+	size_t cap = 0;
+};
+
+} // namespace
+
+struct rtk_mgpu {
+	std::vector<DeviceSlot> slots;
+};
+
+extern "C" void rtk_amd_shard_range(size_t n, int rank, int num_shards, size_t *first, size_t *count)
+{
+	// [floor(r n / R), floor((r + 1) n / R)): the same rule as rtk_amd/shard.py (the per-process RCCL form)
+	size_t f = 0, c = 0;
+	if (num_shards > 0 && rank >= 0 && rank < num_shards) {
+		const unsigned __int128 N = n;
+		f = (size_t)(N * (unsigned)rank / (unsigned)num_shards);
+		c = (size_t)(N * ((unsigned)rank + 1u) / (unsigned)num_shards) - f;
+	}
+	if (first) *first = f;
+	if (count) *count = c;
+}
+
+extern "C" rtk_mgpu *rtk_mgpu_create(const int *devices, int num_devices)
+{
+	int have = 0;
+	if (hipGetDeviceCount(&have) != hipSuccess || have < 1) { rtk_set_error("rtk_mgpu_create: no HIP device"); return nullptr; }
+	if (num_devices <= 0) { num_devices = have; devices = nullptr; }
+	if (num_devices > RTK_MAX_DEVICES) { rtk_set_error("rtk_mgpu_create: too many devices"); return nullptr; }
+	int before = 0;
+	(void)hipGetDevice(&before);
+	rtk_mgpu *m = new rtk_mgpu();
+	m->slots.resize(num_devices);
+	bool ok = true;
+	for (int i = 0; i < num_devices && ok; i++) {
+		DeviceSlot &s = m->slots[i];
+		s.device = devices ? devices[i] : i;
+		if (s.device < 0 || s.device >= have) { rtk_set_error("rtk_mgpu_create: device %d does not exist", s.device); ok = false; break; }
+		ok = hipSetDevice(s.device) == hipSuccess && hipStreamCreateWithFlags(&s.trace_stream, hipStreamNonBlocking) == hipSuccess &&
+			hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) == hipSuccess;
+		if (!ok) rtk_set_error("rtk_mgpu_create: device %d: %s", s.device, hipGetErrorString(hipGetLastError()));
+	}
+	// every GPU may write into every other one's memory (the gather target)
+	for (int i = 0; i < num_devices && ok; i++) {
+		(void)hipSetDevice(m->slots[i].device);
+		for (int j = 0; j < num_devices; j++) {
+			if (m->slots[j].device == m->slots[i].device) continue;
+			const hipError_t e = hipDeviceEnablePeerAccess(m->slots[j].device, 0);
+			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // copies then go through the host; still correct
+		}
+	}
+	(void)hipSetDevice(before);
+	if (!ok) { rtk_mgpu_destroy(m); return nullptr; }
+	return m;
+}
+
+extern "C" void rtk_mgpu_destroy(rtk_mgpu *m)
+{
+	if (!m) return;
+	int before = 0;
+	(void)hipGetDevice(&before);
+	for (DeviceSlot &s : m->slots) {
+		(void)hipSetDevice(s.device);
+		if (s.scene) rtk_dev_scene_free(s.scene);
+		for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
+		if (s.d_rays) (void)hipFree(s.d_rays);
+		if (s.d_rec) (void)hipFree(s.d_rec);
+		if (s.trace_stream) (void)hipStreamDestroy(s.trace_stream);
+		if (s.copy_stream) (void)hipStreamDestroy(s.copy_stream);
+	}
+	(void)hipSetDevice(before);
+	delete m;
+}
+
+extern "C" int rtk_mgpu_num_devices(const rtk_mgpu *m) { return m ? (int)m->slots.size() : 0; }
+
+extern "C" const rtk_dev_scene *rtk_mgpu_scene(const rtk_mgpu *m, int index)
+{
+	return (m && index >= 0 && index < (int)m->slots.size()) ? m->slots[index].scene : nullptr;
+}
+
+static int replicate(rtk_mgpu *m, const rtk_scene_desc *desc, const rtk_scene *blob)
+{
+	if (!m) { rtk_set_error("rtk_mgpu: NULL context"); return RTK_AMD_ERR_BAD_ARG; }
+	int before = 0, rc = RTK_AMD_OK;
+	(void)hipGetDevice(&before);
+	for (DeviceSlot &s : m->slots) {
+		if (hipSetDevice(s.device) != hipSuccess) { rtk_set_error("rtk_mgpu: hipSetDevice(%d) failed", s.device); rc = RTK_AMD_ERR_NO_DEVICE; break; }
+		if (s.scene) rtk_dev_scene_free(s.scene);
+		s.scene = desc ? rtk_dev_scene_build(desc) : rtk_dev_scene_upload(blob);
+		if (!s.scene) { rc = RTK_AMD_ERR_HIP; break; }
+	}
+	(void)hipSetDevice(before);
+	return rc;
+}
+
+extern "C" int rtk_mgpu_build(rtk_mgpu *m, const rtk_scene_desc *desc)
+{
+	if (!desc) { rtk_set_error("rtk_mgpu_build: NULL description"); return RTK_AMD_ERR_BAD_ARG; }
+	return replicate(m, desc, nullptr);
+}
+
+extern "C" int rtk_mgpu_upload(rtk_mgpu *m, const rtk_scene *scene)
+{
+	if (!scene) { rtk_set_error("rtk_mgpu_upload: NULL scene"); return RTK_AMD_ERR_BAD_ARG; }
+	return replicate(m, nullptr, scene);
+}
+
+// Trace shard `i` (rays already on its GPU at d_rays, `count` of them) in pieces; each piece's records are copied to
+// dst + piece offset (host memory, or memory of device dst_device) as soon as that piece is done.
+static int trace_shard(DeviceSlot &s, const rtk_ray *d_rays, size_t count, rtk_hit_record *d_rec, rtk_hit_record *dst, int dst_device,
+	bool dst_is_host, const rtk_trace_opts *opts)
+{
+	const size_t pieces = (count + MGPU_PIECE - 1) / MGPU_PIECE;
+	while (s.events.size() < pieces) {
+		hipEvent_t e;
+		RTK_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming), RTK_AMD_ERR_HIP);
+		s.events.push_back(e);
+	}
+	// an image-shaped shard stays image shaped piece by piece (bands of whole 8-row tile rows), so that the packet
+	// kernel is used; anything else is traced as plain batches
+	rtk_trace_opts band;
+	memset(&band, 0, sizeof(band));
+	const bool image = opts && opts->struct_size >= 16 && opts->image_width && opts->image_height &&
+		(size_t)opts->image_width * opts->image_height == count && opts->image_width % 8u == 0 && opts->image_height % 8u == 0 &&
+		MGPU_PIECE % ((size_t)opts->image_width * 8u) == 0;
+	if (opts) memcpy(&band, opts, opts->struct_size < sizeof(band) ? opts->struct_size : sizeof(band));
+	for (size_t k = 0; k < pieces; k++) {
+		const size_t at = k * MGPU_PIECE, m = count - at < MGPU_PIECE ? count - at : MGPU_PIECE;
+		if (image) band.image_height = (uint32_t)(m / opts->image_width);
+		else { band.image_width = 0; band.image_height = 0; }
+		const rtk_trace_opts *o = opts ? &band : nullptr;
+		const int rc = rtk_launch_trace(s.scene, d_rays + at, m, d_rec + at, nullptr, o, s.trace_stream, false, nullptr);
+		if (rc != RTK_AMD_OK) return rc;
+		RTK_HIP_CHECK(hipEventRecord(s.events[k], s.trace_stream), RTK_AMD_ERR_HIP);
+		RTK_HIP_CHECK(hipStreamWaitEvent(s.copy_stream, s.events[k], 0), RTK_AMD_ERR_HIP);
+		if (dst_is_host) RTK_HIP_CHECK(hipMemcpyAsync(dst + at, d_rec + at, m * sizeof(rtk_hit_record), hipMemcpyDeviceToHost, s.copy_stream), RTK_AMD_ERR_HIP);
+		else if (dst_device == s.device) { if (dst + at != d_rec + at) RTK_HIP_CHECK(hipMemcpyAsync(dst + at, d_rec + at, m * sizeof(rtk_hit_record), hipMemcpyDeviceToDevice, s.copy_stream), RTK_AMD_ERR_HIP); }
+		else RTK_HIP_CHECK(hipMemcpyPeerAsync(dst + at, dst_device, d_rec + at, s.device, m * sizeof(rtk_hit_record), s.copy_stream), RTK_AMD_ERR_HIP);
+	}
+	return RTK_AMD_OK;
+}
+
+static int finish_all(rtk_mgpu *m)
+{
+	int rc = RTK_AMD_OK;
+	for (DeviceSlot &s : m->slots) {
+		if (hipSetDevice(s.device) != hipSuccess || hipStreamSynchronize(s.copy_stream) != hipSuccess) { rtk_set_error("rtk_mgpu: device %d: %s", s.device, hipGetErrorString(hipGetLastError())); rc = RTK_AMD_ERR_HIP; continue; }
+		const int st = rtk_trace_status(s.scene, s.trace_stream);
+		if (st != RTK_AMD_OK) rc = st;
+	}
+	return rc;
+}
+
+extern "C" int rtk_mgpu_trace_rays(rtk_mgpu *m, const rtk_ray *rays, size_t n, rtk_hit_record *records, const rtk_trace_opts *opts)
+{
+	if (!m || (!rays && n) || (!records && n)) { rtk_set_error("rtk_mgpu_trace_rays: NULL argument"); return RTK_AMD_ERR_BAD_ARG; }
+	if (n == 0) return RTK_AMD_OK;
+	const int R = (int)m->slots.size();
+	int before = 0, rc = RTK_AMD_OK;
+	(void)hipGetDevice(&before);
+	for (int r = 0; r < R && rc == RTK_AMD_OK; r++) {
+		DeviceSlot &s = m->slots[r];
+		if (!s.scene) { rtk_set_error("rtk_mgpu_trace_rays: no scene (call rtk_mgpu_build or rtk_mgpu_upload first)"); rc = RTK_AMD_ERR_BAD_ARG; break; }
+		size_t first, count;
+		rtk_amd_shard_range(n, r, R, &first, &count);
+		if (count == 0) continue;
+		if (hipSetDevice(s.device) != hipSuccess) { rc = RTK_AMD_ERR_NO_DEVICE; break; }
+		if (s.cap < count) {
+			if (s.d_rays) (void)hipFree(s.d_rays);
+			if (s.d_rec) (void)hipFree(s.d_rec);
+			s.d_rays = nullptr; s.d_rec = nullptr; s.cap = 0;
+			if (hipMalloc(&s.d_rays, count * sizeof(rtk_ray)) != hipSuccess || hipMalloc(&s.d_rec, count * sizeof(rtk_hit_record)) != hipSuccess) {
+				rtk_set_error("rtk_mgpu_trace_rays: out of device memory on device %d", s.device);
+				rc = RTK_AMD_ERR_OOM; break;
+			}
+			s.cap = count;
+		}
+		if (hipMemcpyAsync(s.d_rays, rays + first, count * sizeof(rtk_ray), hipMemcpyHostToDevice, s.trace_stream) != hipSuccess) { rtk_set_error("rtk_mgpu_trace_rays: H2D copy failed"); rc = RTK_AMD_ERR_HIP; break; }
+		// the whole batch is image shaped only if there is a single shard
+		rc = trace_shard(s, s.d_rays, count, s.d_rec, records + first, -1, true, R == 1 ? opts : nullptr);
+	}
+	const int frc = finish_all(m);
+	(void)hipSetDevice(before);
+	return rc != RTK_AMD_OK ? rc : frc;
+}
+
+extern "C" int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_rays, const size_t *counts, rtk_hit_record *const *d_records,
+	rtk_hit_record *d_gathered, int root_index, const rtk_trace_opts *opts)
+{
+	if (!m || !d_rays || !counts || !d_records) { rtk_set_error("rtk_mgpu_trace_rays_device: NULL argument"); return RTK_AMD_ERR_BAD_ARG; }
+	const int R = (int)m->slots.size();
+	if (d_gathered && (root_index < 0 || root_index >= R)) { rtk_set_error("rtk_mgpu_trace_rays_device: bad root"); return RTK_AMD_ERR_BAD_ARG; }
+	int before = 0, rc = RTK_AMD_OK;
+	(void)hipGetDevice(&before);
+	size_t offset = 0;
+	for (int r = 0; r < R && rc == RTK_AMD_OK; r++) {
+		DeviceSlot &s = m->slots[r];
+		if (!s.scene) { rtk_set_error("rtk_mgpu_trace_rays_device: no scene"); rc = RTK_AMD_ERR_BAD_ARG; break; }
+		if (counts[r] && hipSetDevice(s.device) != hipSuccess) { rc = RTK_AMD_ERR_NO_DEVICE; break; }
+		if (counts[r]) {
+			if (d_gathered) rc = trace_shard(s, d_rays[r], counts[r], d_records[r], d_gathered + offset, m->slots[root_index].device, false, opts);
+			else rc = trace_shard(s, d_rays[r], counts[r], d_records[r], d_records[r], s.device, false, opts);
+		}
+		offset += counts[r];
+	}
+	const int frc = finish_all(m);
+	(void)hipSetDevice(before);
+	return rc != RTK_AMD_OK ? rc : frc;
+}

@@ -60,6 +60,22 @@ __device__ __forceinline__ void load_tri(const char *base, uint32_t a_tri, f32x4
 		: "memory");
 }
 
+// 64 B compressed node (DevNodeQ): four 16-B pieces, one wait.
+__device__ __forceinline__ void load_qnode(const char *base, uint32_t a_node, f32x4 &l0, u32x4 &l1, u32x4 &l2, u32x4 &l3)
+{
+	asm volatile(
+		"global_load_dwordx4 %0, %4, %5\n\t"
+		"global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+		"global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+		"global_load_dwordx4 %3, %4, %5 offset:48\n\t"
+		"s_waitcnt vmcnt(0)"
+		: "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+		: "v"(a_node), "s"(base)
+		: "memory");
+}
+
+__device__ __forceinline__ float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyteK
+
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb)
 {
 	const bool s = kb < ka;
@@ -89,25 +105,16 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 			--sp;                                                                                           \
 			const uint2 e_ = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane]; \
 			if (__uint_as_float(e_.x) > best_t) continue;                                                   \
-			top = e_.y; top_t = __uint_as_float(e_.x);                                                      \
+			top = e_.y;                                                                                     \
 			break;                                                                                          \
 		}                                                                                                   \
-	} while (0)
-
-// POSTPONE: a lane that arrives at a leaf parks it in `pend` and keeps descending from the stack, so that it
-// stays in the node loop with the other lanes; the parked leaf is tested in the next leaf phase. What is
-// visited meanwhile may turn out to lie behind the hit the parked leaf produces (speculation), never the
-// other way round, so results do not change.
-#define RTK_PARK_LEAF()                                                                                     \
-	do {                                                                                                    \
-		if (POSTPONE && pend == RTK_REF_NONE && top != RTK_REF_NONE && (int32_t)top < 0) { pend = top; RTK_POP(); } \
 	} while (0)
 
 #ifndef PL_MIN_WAVES
 #define PL_MIN_WAVES 4             // waves per SIMD the register allocator must leave room for
 #endif
 
-template <int MODE /*0 closest, 1 any*/, bool COUNT, bool FILT /*built-in candidate filters*/, bool POSTPONE /*speculative descent past one leaf*/>
+template <int MODE /*0 closest, 1 any*/, bool COUNT, bool FILT /*built-in candidate filters*/, bool QN /*64 B compressed nodes*/>
 __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(TraceParams p)
 {
 	__shared__ uint2 s_stack[WAVES_PER_BLOCK][LDS_STACK][64];
@@ -117,6 +124,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 	uint2 (*stk)[64] = s_stack[wave];
 	const uint32_t glane = blockIdx.x * BLOCK_THREADS + threadIdx.x;
 	const char *const nodes = reinterpret_cast<const char *>(p.sc.nodes);
+	const char *const qnodes = reinterpret_cast<const char *>(p.sc.qnodes);
 	const char *const tris = reinterpret_cast<const char *>(p.sc.tris);
 
 	// wave-uniform ray range owned by this wave
@@ -140,8 +148,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 	float sox = 0, soy = 0, soz = 0, shx = 0, shy = 0, shz = 0;
 	bool kz0 = false, kz1 = false;
 	uint32_t onx = 0, ony = 0, onz = 0;     // byte offset of the NEAR plane row of each axis inside a node; far = the other row
-	uint32_t pend = RTK_REF_NONE;           // POSTPONE: a leaf whose triangles are still to be tested
-	float top_t = 0.0f;                     // entry distance of `top` (POSTPONE: lets a hit found meanwhile cull it)
 	float best_t = 0, best_u = 0, best_v = 0;
 	uint32_t best_prim = RTK_PRIM_NONE;
 	float after_t = 0;                                    // FILT: candidates must come after (after_t, after_prim)
@@ -228,7 +234,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					}
 					top = 0u;  // root node
 					sp = 0u;
-					pend = RTK_REF_NONE;
 					active = true;
 				}
 				w_next += take;
@@ -247,19 +252,48 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			const bool want_node = active && (int32_t)top >= 0;
 			const unsigned long long m_node = __ballot(want_node);
 			if (m_node == 0ull) break;
-			const bool leaf_waits = POSTPONE ? (active && pend != RTK_REF_NONE) : (active && top != RTK_REF_NONE && (int32_t)top < 0);
-			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(leaf_waits) != 0ull) break;
+			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
 			if (COUNT) w_node_steps++;
 			if (!want_node) continue;
+			uint32_t ref[4];
+			float key[4];
+			uint32_t nhit = 0;
+			if (COUNT) c_nodes++;
+			if (QN && wave_fast) {
+				// Compressed node: plane = org + q * scale, so its ray parameter is A + q * S with A = (org - o) * rcp,
+				// S = scale * rcp. Low planes were rounded down and high planes up when the node was made, so the
+				// decoded slab interval contains the exact one; eps covers the rounding of this arithmetic (about
+				// 2^-22 of the magnitudes involved), so that every child the exact test admits is admitted here too.
+				f32x4 l0;
+				u32x4 l1, l2, l3;
+				load_qnode(qnodes, top << 6, l0, l1, l2, l3);
+				const float Ax = (l0.x - ox) * rdx, Ay = (l0.y - oy) * rdy, Az = (l0.z - oz) * rdz;
+				const float Sx = l0.w * rdx, Sy = __uint_as_float(l1.x) * rdy, Sz = __uint_as_float(l1.y) * rdz;
+				const bool ngx = onx != 0u, ngy = ony != 32u, ngz = onz != 64u;      // direction sign bits
+				const uint32_t wnx = ngx ? l1.w : l1.z, wfx = ngx ? l1.z : l1.w;
+				const uint32_t wny = ngy ? l2.y : l2.x, wfy = ngy ? l2.x : l2.y;
+				const uint32_t wnz = ngz ? l2.w : l2.z, wfz = ngz ? l2.z : l2.w;
+				const float eps = 0x1p-20f * fmaxf(fmaxf(__builtin_fmaf(fabsf(Sx), 255.0f, fabsf(Ax)), __builtin_fmaf(fabsf(Sy), 255.0f, fabsf(Ay))),
+					__builtin_fmaf(fabsf(Sz), 255.0f, fabsf(Az)));
+				ref[0] = l3.x; ref[1] = l3.y; ref[2] = l3.z; ref[3] = l3.w;
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const float ax = __builtin_fmaf(ubyte_f32(wnx, i), Sx, Ax), bx = __builtin_fmaf(ubyte_f32(wfx, i), Sx, Ax);
+					const float ay = __builtin_fmaf(ubyte_f32(wny, i), Sy, Ay), by = __builtin_fmaf(ubyte_f32(wfy, i), Sy, Ay);
+					const float az = __builtin_fmaf(ubyte_f32(wnz, i), Sz, Az), bz = __builtin_fmaf(ubyte_f32(wfz, i), Sz, Az);
+					const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin_ray) - eps;
+					const float tf = fminf(fminf(fminf(bx, by), bz), best_t) + eps;
+					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
+					key[i] = h ? tn : __builtin_inff();
+					nhit += h ? 1u : 0u;
+				}
+			} else {
 			const uint32_t a_node = top << 7;
 			f32x4 nx, fx, ny, fy, nz, fz;
 			u32x4 ch;
 			load_node(nodes, a_node + onx, (a_node + 16u) - onx, a_node + ony, (a_node + 80u) - ony, a_node + onz, (a_node + 144u) - onz, a_node,
 				nx, fx, ny, fy, nz, fz, ch);
-			if (COUNT) c_nodes++;
-			uint32_t ref[4] = { ch.x, ch.y, ch.z, ch.w };
-			float key[4];
-			uint32_t nhit = 0;
+			ref[0] = ch.x; ref[1] = ch.y; ref[2] = ch.z; ref[3] = ch.w;
 			if (wave_fast) {
 				// No NaN can arise for these rays, so min/max are order-free: v_max3/v_min3.
 #pragma unroll
@@ -288,6 +322,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					nhit += h ? 1u : 0u;
 				}
 			}
+			}
 			// nearest first (rtk.c:496-517 orders by entry distance)
 			cswap(key[0], ref[0], key[1], ref[1]);
 			cswap(key[2], ref[2], key[3], ref[3]);
@@ -298,7 +333,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				RTK_POP();
 			} else {
 				top = ref[0];
-				top_t = key[0];
 #pragma unroll
 				for (int i = 3; i >= 1; i--) {
 					if (nhit > (uint32_t)i) {
@@ -307,7 +341,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					}
 				}
 			}
-			RTK_PARK_LEAF();
 		}
 
 		// ---------------------------------------------------------------- leaf
@@ -318,9 +351,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 		// known up front; a zero inside a full group is rare, so the group is simply
 		// redone from a snapshot of the best hit. This keeps t/u/v bit-identical to
 		// rtk.c traversing the same leaves.
-		const uint32_t leaf_ref = POSTPONE ? pend : top;
-		if (active && leaf_ref != RTK_REF_NONE && (int32_t)leaf_ref < 0) {
-			const uint32_t slot0 = leaf_ref & 0x7fffffffu;
+		if (active && top != RTK_REF_NONE && (int32_t)top < 0) {
+			const uint32_t slot0 = top & 0x7fffffffu;
 			if (COUNT) c_leaves++;
 			uint32_t i = 0, n = 1;
 			bool force = false, redo = false;
@@ -407,20 +439,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			}
 			if (MODE == 1 && best_prim != RTK_PRIM_NONE) {
 				top = RTK_REF_NONE;
-				pend = RTK_REF_NONE;
 				sp = 0u;
-			} else if (POSTPONE) {
-				pend = RTK_REF_NONE;
-				// what was popped before this leaf was tested may now start behind the hit
-				if (top != RTK_REF_NONE && top_t > best_t) RTK_POP();
-				RTK_PARK_LEAF();
 			} else {
 				RTK_POP();
 			}
 		}
 
 		// ---------------------------------------------------------------- retire
-		if (active && top == RTK_REF_NONE && (!POSTPONE || pend == RTK_REF_NONE)) {
+		if (active && top == RTK_REF_NONE) {
 			if (MODE == 1) {
 				p.occluded[ray_index] = best_prim != RTK_PRIM_NONE ? 1 : 0;
 			} else {
@@ -538,7 +564,7 @@ namespace {
 
 typedef void (*trace_kernel_fn)(TraceParams);
 
-// variant index: any_hit | counted << 1 | filtered << 2 | postpone << 3
+// variant index: any_hit | counted << 1 | filtered << 2 | compressed nodes << 3
 trace_kernel_fn trace_variant(int v)
 {
 	switch (v) {
@@ -659,11 +685,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 
 	// image-shaped closest-hit batches go to the wave-packet kernel (rtk_trace_packet.hip)
 	const bool packet = !any_hit && !filtered && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
-	static const int postpone_default = getenv("RTK_AMD_POSTPONE") ? atoi(getenv("RTK_AMD_POSTPONE")) : 0;
-	const bool postpone = opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_POSTPONE | RTK_TRACE_NO_POSTPONE))
-		? (opts->flags & RTK_TRACE_POSTPONE) != 0 : postpone_default != 0;
+	// per-lane kernels read the 64 B compressed nodes unless told otherwise (A/B, and tests that compare the two)
+	static const int qnodes_default = getenv("RTK_AMD_QNODES") ? atoi(getenv("RTK_AMD_QNODES")) : 1;
+	const bool qn = ds->view.qnodes != nullptr && qnodes_default != 0 && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_EXACT_NODES));
 	const int variant = packet ? (counted ? VARIANT_PACKET_COUNTED : VARIANT_PACKET)
-		: ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0) | (postpone ? 8 : 0));
+		: ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0) | (qn ? 8 : 0));
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
 

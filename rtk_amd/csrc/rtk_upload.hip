@@ -233,5 +233,9 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h)
 	ds->view.num_nodes = (uint32_t)h.nodes.size();
 	ds->view.num_tris = (uint32_t)h.tris.size();
 	ds->view.num_prims = (uint32_t)prim_slot.size();
+	if (rtk_quantize_nodes(ds, 0) != RTK_AMD_OK || hipStreamSynchronize(0) != hipSuccess) {
+		rtk_dev_scene_free(ds);
+		return nullptr;
+	}
 	return ds;
 }

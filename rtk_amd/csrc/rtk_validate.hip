@@ -21,7 +21,7 @@
 namespace {
 
 enum { C_NODES, C_LEAVES, C_TRIS, C_BOX_VIOLATION, C_LOOSE, C_BAD_REF, C_LEAF_FORMAT, C_TRI_MISSING, C_TRI_DUP,
-	C_NODE_UNREACHED, C_NODE_SHARED, C_PRIM_BAD, C_FIRST_BAD, C_HASH, C_WORDS };
+	C_NODE_UNREACHED, C_NODE_SHARED, C_PRIM_BAD, C_QUANT, C_FIRST_BAD, C_HASH, C_WORDS };
 
 __device__ __forceinline__ void report(unsigned long long *c, int kind, unsigned long long where)
 {
@@ -45,6 +45,22 @@ __global__ void k_check_nodes(DevSceneView sc, uint32_t *slot_seen, uint32_t *no
 	const uint32_t *w = reinterpret_cast<const uint32_t *>(&nd);
 	for (int k = 0; k < 28; k++) h = mix64(h ^ w[k]);          // boxes and child references, not the padding
 	atomicAdd(c + C_HASH, h);
+	if (sc.qnodes) {
+		// the compressed copy of this node: same children, and every decoded box contains the exact one
+		const DevNodeQ qn = sc.qnodes[i];
+		for (int k = 0; k < 4; k++) {
+			bool ok = qn.child[k] == nd.child[k];
+			if (nd.child[k] != RTK_REF_NONE) {
+				const float *lo[3] = { nd.bx[0], nd.by[0], nd.bz[0] }, *hi[3] = { nd.bx[1], nd.by[1], nd.bz[1] };
+				for (int a = 0; a < 3; a++) {
+					const double qlo = (double)qn.org[a] + (double)((qn.q[a][0] >> (8 * k)) & 255u) * (double)qn.scale[a];
+					const double qhi = (double)qn.org[a] + (double)((qn.q[a][1] >> (8 * k)) & 255u) * (double)qn.scale[a];
+					if (!(qlo <= (double)lo[a][k] && qhi >= (double)hi[a][k])) ok = false;
+				}
+			}
+			if (!ok) report(c, C_QUANT, i);
+		}
+	}
 	for (int k = 0; k < 4; k++) {
 		const uint32_t ref = nd.child[k];
 		const float mn[3] = { nd.bx[0][k], nd.by[0][k], nd.bz[0][k] }, mx[3] = { nd.bx[1][k], nd.by[1][k], nd.bz[1][k] };
@@ -157,9 +173,10 @@ extern "C" int rtk_dev_scene_validate(const rtk_dev_scene *ds, rtk_dev_scene_che
 	out->box_violations = h[C_BOX_VIOLATION]; out->loose_boxes = h[C_LOOSE]; out->bad_references = h[C_BAD_REF];
 	out->leaf_format_errors = h[C_LEAF_FORMAT]; out->triangles_missing = h[C_TRI_MISSING]; out->triangles_duplicated = h[C_TRI_DUP];
 	out->nodes_unreachable = h[C_NODE_UNREACHED]; out->nodes_shared = h[C_NODE_SHARED]; out->primitive_id_errors = h[C_PRIM_BAD];
+	out->compressed_node_errors = h[C_QUANT];
 	out->first_bad_index = h[C_FIRST_BAD]; out->content_hash = h[C_HASH];
 	const unsigned long long bad = h[C_BOX_VIOLATION] + h[C_BAD_REF] + h[C_LEAF_FORMAT] + h[C_TRI_MISSING] + h[C_TRI_DUP] +
-		h[C_NODE_UNREACHED] + h[C_NODE_SHARED] + h[C_PRIM_BAD];
+		h[C_NODE_UNREACHED] + h[C_NODE_SHARED] + h[C_PRIM_BAD] + h[C_QUANT];
 	if (bad) {
 		rtk_set_error("rtk_dev_scene_validate: %llu structural errors (first at index %llu)", bad, h[C_FIRST_BAD]);
 		return RTK_AMD_ERR_BAD_SCENE;

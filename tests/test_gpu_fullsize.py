@@ -67,8 +67,7 @@ def test_incoherent_full_batch(api, scene):
     nhit = _check_geometry(tris, rays, rec)
     assert nhit / N > 0.99
     assert ds.trace(rays, opts=api.make_opts(static=True, node_exit=1), full=False).tobytes() == rec.tobytes()
-    assert ds.trace(rays, opts=api.make_opts(postpone=True), full=False).tobytes() == rec.tobytes()
-    assert ds.trace(rays, opts=api.make_opts(postpone=False), full=False).tobytes() == rec.tobytes()
+    assert ds.trace(rays, opts=api.make_opts(exact_nodes=True), full=False).tobytes() == rec.tobytes()
 
 
 def _check_near_ties(g, cfg, rec, what):

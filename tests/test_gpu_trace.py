@@ -72,7 +72,7 @@ def test_edge_cases_vs_golden(api, oracle, golden_dir):
 
 
 @pytest.mark.parametrize("mode", ["static", "refill8", "tiled", "tiled_per_lane", "node_exit16", "node_exit64_refill8", "node_exit64_static",
-                                  "sort_rays", "sort_rays_static", "postpone", "no_postpone", "postpone_static_exit1", "postpone_exit64"])
+                                  "sort_rays", "sort_rays_static", "exact_nodes", "exact_nodes_static_exit1"])
 def test_launch_modes_agree(api, scene1, mode):
     _, ds = scene1
     rays = synth.rays_config1(65536)
@@ -87,14 +87,10 @@ def test_launch_modes_agree(api, scene1, mode):
         opts = api.make_opts(sort_rays=True)
     elif mode == "sort_rays_static":
         opts = api.make_opts(sort_rays=True, static=True)
-    elif mode == "postpone":
-        opts = api.make_opts(postpone=True)
-    elif mode == "no_postpone":
-        opts = api.make_opts(postpone=False)
-    elif mode == "postpone_static_exit1":
-        opts = api.make_opts(postpone=True, static=True, node_exit=1)
-    elif mode == "postpone_exit64":
-        opts = api.make_opts(postpone=True, node_exit=64, refill_min=8)
+    elif mode == "exact_nodes":
+        opts = api.make_opts(exact_nodes=True)
+    elif mode == "exact_nodes_static_exit1":
+        opts = api.make_opts(exact_nodes=True, static=True, node_exit=1)
     elif mode == "node_exit16":
         opts = api.make_opts(node_exit=16)
     elif mode == "node_exit64_refill8":
@@ -139,8 +135,7 @@ def test_any_hit_equals_closest_hit_boolean(api, scene1):
     occ = ds.trace_any(rays)
     assert (occ == (rec["prim"] != 0xFFFFFFFF)).all()
     assert 0 < occ.sum() < len(occ)
-    for postpone in (True, False):
-        assert (ds.trace_any(rays, opts=api.make_opts(postpone=postpone)) == occ).all()
+    assert (ds.trace_any(rays, opts=api.make_opts(exact_nodes=True)) == occ).all()
 
 
 def test_single_ray_and_host_batch_entry_points(api, oracle, scene1, golden_dir):
