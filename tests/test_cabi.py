@@ -123,3 +123,22 @@ def test_blob_validator_rejects_corrupt_scenes_without_a_gpu(oracle):
     if not torch.cuda.is_available():
         h, err = upload(good)
         assert not h and "HIP device" in err
+
+
+def test_c_shard_range_equals_the_python_rule():
+    """rtk_amd_shard_range (the C host's partitioning, rtk_mgpu.hip) == rtk_amd.shard.shard_range (bench.py --gpus N)."""
+    from rtk_amd import shard
+    L = api.lib()
+    f, c = C.c_size_t(), C.c_size_t()
+    for n in (0, 1, 7, 64, 1000, 16777216, 16777217, 134217728, 2 ** 40 + 3):
+        for world in (1, 2, 3, 4, 7, 8):
+            end = 0
+            for r in range(world):
+                L.rtk_amd_shard_range(n, r, world, C.byref(f), C.byref(c))
+                b, e = shard.shard_range(n, r, world)
+                assert (f.value, f.value + c.value) == (b, e)
+                assert f.value == end
+                end = f.value + c.value
+            assert end == n
+    L.rtk_amd_shard_range(100, 5, 4, C.byref(f), C.byref(c))      # out-of-range rank: empty
+    assert c.value == 0

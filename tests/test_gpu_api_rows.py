@@ -347,3 +347,52 @@ def test_residency_cache_notices_a_new_blob_at_the_same_address(api, oracle):
     oh, om = oracle.trace(blob, rays)
     assert (mask == om).all() and (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
     L.rtk_amd_forget_scene(C.c_void_p(buf.ctypes.data))
+
+
+def test_single_process_multi_gpu_context_with_virtual_shards(api, oracle):
+    """rtk_mgpu_* (the C host's form of SURVEY.md 8e): the scene replicated on every slot, the batch cut into
+    contiguous ranges, records gathered by per-slot copies. One physical GPU here, so the context is made of
+    three slots on device 0 -- the sharding, the piecewise trace + copy pipeline and the gather are the real code."""
+    import torch
+    from rtk_amd.types import HIT_RECORD_DTYPE, MeshSet
+    L = api.lib()
+    tris = synth.scene_for_config(1)
+    devs = (C.c_int * 3)(0, 0, 0)
+    m = L.rtk_mgpu_create(devs, 3)
+    assert m and L.rtk_mgpu_num_devices(m) == 3
+    try:
+        ms = MeshSet([dict(positions=tris)])
+        assert L.rtk_mgpu_build(m, C.byref(ms.desc)) == 0, api.last_error()
+        # every replica is the same tree
+        hashes = set()
+        for i in range(3):
+            c = api.SceneCheck()
+            assert L.rtk_dev_scene_validate(L.rtk_mgpu_scene(m, i), C.byref(c)) == 0
+            hashes.add(c.content_hash)
+        assert len(hashes) == 1
+        ref = api.DeviceScene.build([dict(positions=tris)])
+        # host rays in, host records out; a size that does not divide by 3 and spans several pieces
+        n = (1 << 22) + 12345
+        rays = np.concatenate([synth.rays_config1(1 << 20, seed=s) for s in (2, 3, 4, 5, 6)])[:n]
+        want = ref.trace(rays, full=False)
+        got = np.zeros(n, HIT_RECORD_DTYPE)
+        assert L.rtk_mgpu_trace_rays(m, rays.ctypes.data, n, got.ctypes.data, None) == 0, api.last_error()
+        assert got.tobytes() == want.tobytes()
+        # device-resident shards gathered onto slot 1; each shard an image-shaped frame -> packet kernel in bands
+        frames = [synth.rays_pinhole(2048, 2048, jitter=synth.frame_jitter(k)) for k in range(3)]
+        d_rays = [api.to_device(f) for f in frames]
+        d_rec = [torch.empty(len(f) * 16, dtype=torch.uint8, device="cuda") for f in frames]
+        d_all = torch.zeros(3 * 2048 * 2048 * 16, dtype=torch.uint8, device="cuda")
+        rp = (C.c_void_p * 3)(*[t.data_ptr() for t in d_rays])
+        cp = (C.c_size_t * 3)(*[len(f) for f in frames])
+        op = (C.c_void_p * 3)(*[t.data_ptr() for t in d_rec])
+        opts = api.make_opts(image=(2048, 2048))
+        torch.cuda.synchronize()
+        assert L.rtk_mgpu_trace_rays_device(m, rp, cp, op, C.c_void_p(d_all.data_ptr()), 1, C.byref(opts)) == 0, api.last_error()
+        allrec = d_all.cpu().numpy().view(HIT_RECORD_DTYPE)
+        for k, f in enumerate(frames):
+            w = ref.trace(f, opts=opts, full=False)
+            assert allrec[k * len(f):(k + 1) * len(f)].tobytes() == w.tobytes()
+            assert d_rec[k].cpu().numpy().tobytes() == w.tobytes()
+    finally:
+        L.rtk_mgpu_destroy(m)
