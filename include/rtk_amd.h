@@ -141,6 +141,15 @@ typedef struct rtk_dev_scene_check {
 } rtk_dev_scene_check;
 int rtk_dev_scene_validate(const rtk_dev_scene *ds, rtk_dev_scene_check *out);
 
+/* Which builder rtk_start_build / rtk_build_scene use (rtk.h:119-126). Default: the device LBVH build, a graph of
+ * ONE task. RTK_AMD_BUILDER_CPU_TASKS selects the reference's caller-scheduled task graph on the CPU (rtk.c:1362-1507:
+ * <= 128 triangle-setup tasks, one binned-SAH task per node, vertex-group finalisation), so a host's own scheduler
+ * keeps driving a real graph from any number of threads; it needs no GPU to BUILD (tracing the blob still does).
+ * Never selected implicitly. Environment RTK_AMD_BUILDER=cpu is read once if this was never called. */
+enum { RTK_AMD_BUILDER_DEVICE = 0, RTK_AMD_BUILDER_CPU_TASKS = 1 };
+int rtk_amd_set_builder(int builder);
+int rtk_amd_get_builder(void);
+
 /* Device builds draw their temporaries from one workspace per device that is kept between builds
  * (about 330 bytes per triangle); this releases it. */
 void rtk_amd_release_workspace(void);

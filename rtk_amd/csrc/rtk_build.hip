@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <unordered_map>
@@ -1477,11 +1478,42 @@ extern "C" rtk_scene *rtk_dev_scene_export(const rtk_dev_scene *ds, void *buffer
 // parallelism is inside the GPU, so the graph has exactly one task: running it performs the
 // whole device build. Callers that loop "while tasks remain: rtk_run_task" work unchanged.
 
+// -- the CPU task-graph builder (rtk_cpu_build.cpp), selected explicitly by the host --
+struct rtk_cpu_build;
+void rtk_cpu_task_start(const rtk_task *, rtk_task_ctx *);
+rtk_cpu_build *rtk_cpu_build_start(const rtk_scene_desc *desc, void *owner, rtk_task *first_task, rtk_task_fn *runner);
+size_t rtk_cpu_build_run(rtk_cpu_build *b, const rtk_task *task, bool start, rtk_task *queue, size_t queue_size);
+bool rtk_cpu_build_done(const rtk_cpu_build *b);
+size_t rtk_cpu_build_size(rtk_cpu_build *b);
+bool rtk_cpu_build_write(rtk_cpu_build *b, void *buffer, size_t size);
+void rtk_cpu_build_free(rtk_cpu_build *b);
+
 struct rtk_build {
 	rtk_scene_desc desc;
-	rtk_dev_scene *scene;
+	rtk_dev_scene *scene;      // device builder: the built scene
 	bool done;
+	rtk_cpu_build *cpu;        // CPU task-graph builder, or NULL
 };
+
+static std::atomic<int> g_builder{ -1 };
+
+extern "C" int rtk_amd_set_builder(int builder)
+{
+	if (builder != RTK_AMD_BUILDER_DEVICE && builder != RTK_AMD_BUILDER_CPU_TASKS) { rtk_set_error("rtk_amd_set_builder: unknown builder %d", builder); return RTK_AMD_ERR_BAD_ARG; }
+	g_builder.store(builder);
+	return RTK_AMD_OK;
+}
+
+extern "C" int rtk_amd_get_builder(void)
+{
+	int b = g_builder.load();
+	if (b < 0) {
+		const char *e = getenv("RTK_AMD_BUILDER");
+		b = (e && (!strcmp(e, "cpu") || !strcmp(e, "cpu-tasks"))) ? RTK_AMD_BUILDER_CPU_TASKS : RTK_AMD_BUILDER_DEVICE;
+		g_builder.store(b);
+	}
+	return b;
+}
 
 static void build_task_fn(const rtk_task *task, rtk_task_ctx *)
 {
@@ -1498,6 +1530,26 @@ extern "C" rtk_build *rtk_start_build(const rtk_scene_desc *desc, rtk_task *firs
 	b->desc = *desc;              // by value; meshes stay borrowed (rtk.c:1661)
 	b->scene = nullptr;
 	b->done = false;
+	b->cpu = nullptr;
+	if (rtk_amd_get_builder() == RTK_AMD_BUILDER_CPU_TASKS) {
+		// the reference's caller-scheduled task graph (rtk.c:1362-1507)
+		rtk_task first;
+		memset(&first, 0, sizeof(first));
+		b->cpu = rtk_cpu_build_start(desc, b, first_task ? first_task : &first, nullptr);
+		if (!b->cpu) { delete b; return nullptr; }
+		if (!first_task) {
+			// the inline path the reference leaves as a TODO (rtk.c:1682-1688, B8): a serial scheduler
+			std::vector<rtk_task> queue(1, first), spawned(256);
+			while (!queue.empty()) {
+				const rtk_task t = queue.back();
+				queue.pop_back();
+				const size_t n = rtk_run_task(&t, spawned.data(), spawned.size());
+				queue.insert(queue.end(), spawned.begin(), spawned.begin() + n);
+			}
+			if (!rtk_cpu_build_done(b->cpu)) { rtk_set_error("rtk_start_build: task graph did not complete"); rtk_cpu_build_free(b->cpu); delete b; return nullptr; }
+		}
+		return b;
+	}
 	if (first_task) {
 		first_task->build = b;    // rtk.c:1679-1681
 		first_task->fn = &build_task_fn;
@@ -1517,20 +1569,28 @@ extern "C" rtk_build *rtk_start_build(const rtk_scene_desc *desc, rtk_task *firs
 
 extern "C" size_t rtk_run_task(const rtk_task *task, rtk_task *queue, size_t queue_size)
 {
-	(void)queue; (void)queue_size;
 	if (!task || !task->fn) return 0;
-	task->fn(task, nullptr);
-	return 0;                     // no follow-up tasks
+	if (task->build && task->build->cpu)
+		return rtk_cpu_build_run(task->build->cpu, task, task->fn == &rtk_cpu_task_start, queue, queue ? queue_size : 0);
+	task->fn(task, nullptr);      // device builder: one task does the whole build, nothing follows
+	return 0;
 }
 
 extern "C" size_t rtk_get_build_size(const rtk_build *build)
 {
+	if (build && build->cpu) return rtk_cpu_build_size(build->cpu);
 	if (!build || !build->scene) { rtk_set_error("rtk_get_build_size: build has not run (or failed)"); return 0; }
 	return rtk_dev_scene_export_size(build->scene);
 }
 
 extern "C" rtk_scene *rtk_finish_build_to(rtk_build *build, void *buffer, size_t size)
 {
+	if (build && build->cpu) {
+		if (!buffer || !rtk_cpu_build_write(build->cpu, buffer, size)) return nullptr;      // too small: the build stays alive (rtk.c:1735)
+		rtk_cpu_build_free(build->cpu);
+		delete build;                                                                        // rtk.c:1771
+		return (rtk_scene *)buffer;
+	}
 	if (!build || !build->scene || !buffer) { rtk_set_error("rtk_finish_build_to: build has not run (or failed)"); return nullptr; }
 	const size_t need = rtk_dev_scene_export_size(build->scene);
 	if (need == 0 || size < need) return nullptr;             // build stays alive (rtk.c:1735)
@@ -1544,15 +1604,18 @@ extern "C" rtk_scene *rtk_finish_build_to(rtk_build *build, void *buffer, size_t
 extern "C" rtk_scene *rtk_finish_build(rtk_build *build)
 {
 	if (!build) return nullptr;
-	const size_t need = build->scene ? rtk_dev_scene_export_size(build->scene) : 0;
+	const size_t need = rtk_get_build_size(build);
 	void *buffer = need ? aligned_alloc(128, align_up(need, 128)) : nullptr;
 	if (!buffer) {                                            // rtk.c:1779-1783: free the build, return NULL
 		if (build->scene) rtk_dev_scene_free(build->scene);
+		if (build->cpu) rtk_cpu_build_free(build->cpu);
 		delete build;
 		return nullptr;
 	}
+	rtk_dev_scene *scene = build->scene;
+	rtk_cpu_build *cpu = build->cpu;
 	rtk_scene *s = rtk_finish_build_to(build, buffer, need);
-	if (!s) { free(buffer); if (build->scene) rtk_dev_scene_free(build->scene); delete build; }
+	if (!s) { free(buffer); if (scene) rtk_dev_scene_free(scene); if (cpu) rtk_cpu_build_free(cpu); delete build; }
 	return s;
 }
 

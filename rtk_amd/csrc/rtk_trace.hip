@@ -262,27 +262,32 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			if (QN && wave_fast) {
 				// Compressed node: plane = org + q * scale, so its ray parameter is A + q * S with A = (org - o) * rcp,
 				// S = scale * rcp. Low planes were rounded down and high planes up when the node was made, so the
-				// decoded slab interval contains the exact one; eps covers the rounding of this arithmetic (about
-				// 2^-22 of the magnitudes involved), so that every child the exact test admits is admitted here too.
+				// decoded slab interval contains the exact one; a small margin covers the rounding of this arithmetic,
+				// so that every child the exact test admits is admitted here too.
 				f32x4 l0;
 				u32x4 l1, l2, l3;
 				load_qnode(qnodes, top << 6, l0, l1, l2, l3);
 				const float Ax = (l0.x - ox) * rdx, Ay = (l0.y - oy) * rdy, Az = (l0.z - oz) * rdz;
 				const float Sx = l0.w * rdx, Sy = __uint_as_float(l1.x) * rdy, Sz = __uint_as_float(l1.y) * rdz;
+				// per axis: the rounding of A + q * S (and of the exact test it stands in for) is below 2^-22 of
+				// |A| + 255 |S|; near planes start from A - e, far planes from A + e. Per AXIS on purpose: one tiny
+				// direction component makes that axis' A and S huge, and a common margin would open every box.
+				const float ex = 0x1p-21f * __builtin_fmaf(fabsf(Sx), 255.0f, fabsf(Ax));
+				const float ey = 0x1p-21f * __builtin_fmaf(fabsf(Sy), 255.0f, fabsf(Ay));
+				const float ez = 0x1p-21f * __builtin_fmaf(fabsf(Sz), 255.0f, fabsf(Az));
+				const float Anx = Ax - ex, Afx = Ax + ex, Any = Ay - ey, Afy = Ay + ey, Anz = Az - ez, Afz = Az + ez;
 				const bool ngx = onx != 0u, ngy = ony != 32u, ngz = onz != 64u;      // direction sign bits
 				const uint32_t wnx = ngx ? l1.w : l1.z, wfx = ngx ? l1.z : l1.w;
 				const uint32_t wny = ngy ? l2.y : l2.x, wfy = ngy ? l2.x : l2.y;
 				const uint32_t wnz = ngz ? l2.w : l2.z, wfz = ngz ? l2.z : l2.w;
-				const float eps = 0x1p-20f * fmaxf(fmaxf(__builtin_fmaf(fabsf(Sx), 255.0f, fabsf(Ax)), __builtin_fmaf(fabsf(Sy), 255.0f, fabsf(Ay))),
-					__builtin_fmaf(fabsf(Sz), 255.0f, fabsf(Az)));
 				ref[0] = l3.x; ref[1] = l3.y; ref[2] = l3.z; ref[3] = l3.w;
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
-					const float ax = __builtin_fmaf(ubyte_f32(wnx, i), Sx, Ax), bx = __builtin_fmaf(ubyte_f32(wfx, i), Sx, Ax);
-					const float ay = __builtin_fmaf(ubyte_f32(wny, i), Sy, Ay), by = __builtin_fmaf(ubyte_f32(wfy, i), Sy, Ay);
-					const float az = __builtin_fmaf(ubyte_f32(wnz, i), Sz, Az), bz = __builtin_fmaf(ubyte_f32(wfz, i), Sz, Az);
-					const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin_ray) - eps;
-					const float tf = fminf(fminf(fminf(bx, by), bz), best_t) + eps;
+					const float ax = __builtin_fmaf(ubyte_f32(wnx, i), Sx, Anx), bx = __builtin_fmaf(ubyte_f32(wfx, i), Sx, Afx);
+					const float ay = __builtin_fmaf(ubyte_f32(wny, i), Sy, Any), by = __builtin_fmaf(ubyte_f32(wfy, i), Sy, Afy);
+					const float az = __builtin_fmaf(ubyte_f32(wnz, i), Sz, Anz), bz = __builtin_fmaf(ubyte_f32(wfz, i), Sz, Afz);
+					const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin_ray);
+					const float tf = fminf(fminf(fminf(bx, by), bz), best_t);
 					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
 					key[i] = h ? tn : __builtin_inff();
 					nhit += h ? 1u : 0u;

@@ -322,3 +322,28 @@ def test_default_index_type_means_u32(api):
     a = np.frombuffer(recs[0], dtype=ref.trace(rays, full=False).dtype)
     b = ref.trace(rays, full=False)
     assert (a["prim"] == b["prim"]).all() and (a["t"] == b["t"]).all()
+
+
+def test_cpu_task_builder_blob_on_the_device(api, oracle, golden_dir):
+    """The CPU task-graph builder (rtk_amd_set_builder) + the GPU tracer: rtk_build_scene -> rtk_trace_rays, the device
+    validator on the uploaded blob, hits equal to the reference fixture and to the oracle on the same blob."""
+    L = api.lib()
+    assert L.rtk_amd_set_builder(1) == 0
+    try:
+        tris = synth.scene_for_config(1)
+        scene, keep = api.build_scene([dict(positions=tris)])
+    finally:
+        L.rtk_amd_set_builder(0)
+    try:
+        blob = _as_blob(oracle, api.scene_bytes(scene))
+        assert oracle.validate_blob(blob)[0] == 0
+        ds = api.DeviceScene.upload(blob)
+        ok, c = ds.validate()
+        assert ok and c["triangles_checked"] == 10000 and c["loose_boxes"] == 0, c
+        rays = synth.rays_config1(65536)
+        hits, mask, _ = _same_as_oracle(oracle, blob, ds, rays, "cpu-built blob on the device")
+        compare_hits_struct(hits, mask, load_golden(golden_dir, "cfg1_full.npz"), "cpu-built blob vs reference fixture")
+        h2, m2 = api.trace_rays(scene, rays[:4096])
+        assert (m2 == mask[:4096]).all() and (h2["triangle_index"][m2] == hits["triangle_index"][:4096][m2]).all()
+    finally:
+        api.free_scene(scene)
