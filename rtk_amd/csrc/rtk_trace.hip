@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					__builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
 				if (!active && rank < take) {
-					ray_index = p.perm ? p.perm[w_next + rank] : (uint32_t)map_index(w_next + rank, p.image_w, p.image_h);
+					ray_index = p.perm ? p.perm[w_next + rank] : (uint32_t)map_index(w_next + rank, p.image_w, p.image_h, p.tile_blocks);
 					const float4 r0 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index));
 					const float4 r1 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
 					ox = r0.x; oy = r0.y; oz = r0.z;
@@ -677,6 +677,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		}
 		if (opts->struct_size >= 28 && opts->node_exit) p.node_exit = opts->node_exit > 64 ? 64 : opts->node_exit;
 	}
+	static const int tile_blocks_default = getenv("RTK_AMD_TILE_BLOCKS") ? atoi(getenv("RTK_AMD_TILE_BLOCKS")) : 1;
+	p.tile_blocks = (tile_blocks_default && p.image_w && p.image_w % 64u == 0 && p.image_h % 64u == 0) ? 1u : 0u;
 	bool filtered = false;
 	if (filter) {
 		if (filter->struct_size < sizeof(rtk_dev_filter)) { rtk_set_error("rtk_dev_trace: rtk_dev_filter.struct_size is too small"); return RTK_AMD_ERR_BAD_ARG; }

@@ -28,7 +28,7 @@
 #define PK_LDS_STACK 16            // per-lane entry distances held in LDS
 #define PK_WAVE_STACK 64           // wave-uniform references held in one VGPR
 #ifndef PK_MIN_WAVES
-#define PK_MIN_WAVES 5             // waves per SIMD the register allocator must leave room for
+#define PK_MIN_WAVES 6             // waves per SIMD the register allocator must leave room for: 80 VGPRs (3 spilled to scratch), measured +5 % over 5
 #endif
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -273,7 +273,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			if (lane == 0) got = atomicAdd(p.counter + RTK_QUEUE_WORD(queue), 1ull);
 			got = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32)) << 32) |
 				(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
-			tile = got * RTK_QUEUES + queue;
+			// tile_blocks: a queue hands out the 64 tiles of one 64x64-pixel block one after the other (blocks are dealt
+			// round robin over the queues); otherwise single tiles are dealt round robin
+			tile = p.tile_blocks ? ((((got >> 6) * RTK_QUEUES + queue) << 6) | (got & 63ull)) : got * RTK_QUEUES + queue;
 			if (tile < num_tiles) { have = true; break; }
 			queue = (queue + 1u) % RTK_QUEUES;       // this queue is drained for good
 			queues_left--;
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 		const unsigned long long base = tile << 6;
 		const unsigned long long idx = base + lane;
 		const bool alive = idx < p.n;
-		const unsigned long long ray_index = map_index(alive ? idx : base, p.image_w, p.image_h);
+		const unsigned long long ray_index = map_index(alive ? idx : base, p.image_w, p.image_h, p.tile_blocks);
 
 		PkLane L;
 		{

@@ -30,6 +30,7 @@ struct TraceParams {
 	const uint32_t *ignore_prim;   // per ray: global primitive id that is never a candidate
 	const uint32_t *mesh_mask;     // bit m set = triangles of mesh m are candidates
 	uint32_t mesh_mask_bits;       // meshes covered by mesh_mask; meshes beyond it are not candidates
+	uint32_t tile_blocks;          // image batches: tiles are numbered block by block (8x8 tiles = 64x64 pixels), not row by row
 };
 
 // DevTri.flags: bit 0 = last triangle of its leaf, bits 8.. = mesh index (for the mesh-mask filter)
@@ -41,14 +42,27 @@ __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : 
 
 
 // Row-major image -> 8x8 pixel tiles, so that the 64 lanes of a wave share BVH nodes.
-__device__ __forceinline__ unsigned long long map_index(unsigned long long i, uint32_t w, uint32_t h)
+// With `blocks` the tiles themselves are numbered block by block (64 consecutive tiles = one 64x64 pixel block), so that
+// the tiles a work queue hands out one after the other -- to waves that run at the same time on one XCD -- are
+// neighbours in the image and walk the same part of the tree (L2 / scalar cache hits instead of fabric traffic).
+__device__ __forceinline__ unsigned long long map_index(unsigned long long i, uint32_t w, uint32_t h, uint32_t blocks = 0)
 {
 	if (w == 0) return i;
 	const unsigned long long tile = i >> 6;
 	const uint32_t in = (uint32_t)i & 63u;
 	const uint32_t tiles_per_row = w >> 3;
-	const unsigned long long ty = tile / tiles_per_row;
-	const uint32_t tx = (uint32_t)(tile - ty * tiles_per_row);
+	unsigned long long ty;
+	uint32_t tx;
+	if (blocks) {
+		const unsigned long long blk = tile >> 6;
+		const uint32_t b = (uint32_t)tile & 63u, blocks_per_row = w >> 6;
+		const unsigned long long by = blk / blocks_per_row;
+		tx = (uint32_t)(blk - by * blocks_per_row) * 8u + (b & 7u);
+		ty = by * 8u + (b >> 3);
+	} else {
+		ty = tile / tiles_per_row;
+		tx = (uint32_t)(tile - ty * tiles_per_row);
+	}
 	const unsigned long long x = (unsigned long long)tx * 8u + (in & 7u);
 	const unsigned long long y = ty * 8u + (in >> 3);
 	return y * w + x;
