@@ -1,0 +1,327 @@
+// BVH quality lab (CPU, throw-away): binary builders (LBVH, PLOC) -> SAH leaf decision -> greedy BVH4 collapse
+// -> ordered closest-hit traversal counting node/leaf/triangle visits per ray.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <chrono>
+
+struct Box { float mn[3], mx[3]; };
+static inline Box merge(const Box &a, const Box &b) { Box r; for (int k = 0; k < 3; k++) { r.mn[k] = std::min(a.mn[k], b.mn[k]); r.mx[k] = std::max(a.mx[k], b.mx[k]); } return r; }
+static inline float harea(const Box &b) { float x = b.mx[0] - b.mn[0], y = b.mx[1] - b.mn[1], z = b.mx[2] - b.mn[2]; return x * y + y * z + z * x; }
+
+struct Ray { float o[3], d[3], tmin, tmax; };
+
+static int KEYSHIFT = 0;
+static std::vector<float> tris;   // 9 per tri
+static size_t N;
+
+static uint64_t spread21(uint32_t v) {
+	uint64_t x = v & 0x1fffffu;
+	x = (x | (x << 32)) & 0x1f00000000ffffull; x = (x | (x << 16)) & 0x1f0000ff0000ffull; x = (x | (x << 8)) & 0x100f00f00f00f00full;
+	x = (x | (x << 4)) & 0x10c30c30c30c30c3ull; x = (x | (x << 2)) & 0x1249249249249249ull; return x;
+}
+
+// binary tree: nodes 0..n-2 inner; child >=0 inner, <0 leaf ~sorted_index
+struct Bin { int l, r; Box b; uint32_t cnt; float cost; bool leaf; };
+static std::vector<Bin> bin; static int root;
+static std::vector<uint32_t> order;  // sorted index -> prim
+static std::vector<Box> pbox;        // per sorted index
+static std::vector<uint64_t> keys;
+
+static void morton_sort() {
+	std::vector<float> c2(3 * N);
+	float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+	std::vector<Box> pb(N);
+	for (size_t i = 0; i < N; i++) {
+		const float *p = &tris[9 * i];
+		for (int a = 0; a < 3; a++) {
+			float mn = std::min(std::min(p[a], p[3 + a]), p[6 + a]), mx = std::max(std::max(p[a], p[3 + a]), p[6 + a]);
+			pb[i].mn[a] = mn; pb[i].mx[a] = mx; c2[3 * i + a] = mn + mx; lo[a] = std::min(lo[a], mn + mx); hi[a] = std::max(hi[a], mn + mx);
+		}
+	}
+	std::vector<std::pair<uint64_t, uint32_t>> kv(N);
+	for (size_t i = 0; i < N; i++) {
+		uint32_t q[3];
+		for (int a = 0; a < 3; a++) { float ext = hi[a] - lo[a]; float t = ext > 0 ? (c2[3 * i + a] - lo[a]) / ext : 0; t = std::min(std::max(t, 0.f), 1.f); uint32_t v = (uint32_t)(t * 2097152.0f); q[a] = v > 2097151u ? 2097151u : v; }
+		kv[i] = { ((spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2])) >> KEYSHIFT, (uint32_t)i };
+	}
+	std::stable_sort(kv.begin(), kv.end(), [](auto &a, auto &b) { return a.first < b.first; });
+	order.resize(N); pbox.resize(N); keys.resize(N);
+	for (size_t i = 0; i < N; i++) { order[i] = kv[i].second; pbox[i] = pb[kv[i].second]; keys[i] = kv[i].first; }
+}
+
+// ---- LBVH (same topology as Karras): recursive split at highest differing bit; equal keys split by index bits
+static int lbvh_rec(int lo, int hi) {   // returns child ref
+	if (lo == hi) return ~lo;
+	int split;
+	uint64_t a = keys[lo], b = keys[hi];
+	if (a == b) {
+		// karras uses index as tiebreak: delta = 64 + clz(i^j)
+		int pre = __builtin_clz((unsigned)(lo ^ hi));
+		// find largest s in [lo,hi) with clz(lo ^ s) > pre
+		int s = lo; int step = hi - lo;
+		do { step = (step + 1) >> 1; int ns = s + step; if (ns < hi && __builtin_clz((unsigned)(lo ^ ns)) > pre) s = ns; } while (step > 1);
+		split = s;
+	} else {
+		int pre = __builtin_clzll(a ^ b);
+		int s = lo; int step = hi - lo;
+		do { step = (step + 1) >> 1; int ns = s + step; if (ns < hi) { uint64_t k = keys[ns]; int d = (k == a) ? 64 + __builtin_clz((unsigned)(lo ^ ns)) : __builtin_clzll(a ^ k); if (d > pre) s = ns; } } while (step > 1);
+		split = s;
+	}
+	int id = (int)bin.size(); bin.push_back(Bin());
+	int l = lbvh_rec(lo, split), r = lbvh_rec(split + 1, hi);
+	bin[id].l = l; bin[id].r = r;
+	return id;
+}
+
+static void refit_rec(int id) {
+	Bin &n = bin[id];
+	Box b[2]; uint32_t c[2];
+	for (int s = 0; s < 2; s++) { int ch = s ? n.r : n.l; if (ch < 0) { b[s] = pbox[~ch]; c[s] = 1; } else { refit_rec(ch); b[s] = bin[ch].b; c[s] = bin[ch].cnt; } }
+	n.b = merge(b[0], b[1]); n.cnt = c[0] + c[1];
+}
+
+// ---- PLOC
+static void build_ploc(int R) {
+	bin.clear(); bin.reserve(N);
+	struct Cl { Box b; int ref; };
+	std::vector<Cl> C(N), C2;
+	for (size_t i = 0; i < N; i++) { C[i].b = pbox[i]; C[i].ref = ~(int)i; }
+	std::vector<int> nn;
+	int iters = 0;
+	while (C.size() > 1) {
+		int m = (int)C.size();
+		nn.assign(m, -1);
+		for (int i = 0; i < m; i++) {
+			float best = INFINITY; int bj = -1;
+			int j0 = std::max(0, i - R), j1 = std::min(m - 1, i + R);
+			for (int j = j0; j <= j1; j++) { if (j == i) continue; float a = harea(merge(C[i].b, C[j].b)); if (a < best) { best = a; bj = j; } }
+			nn[i] = bj;
+		}
+		C2.clear();
+		for (int i = 0; i < m; i++) {
+			int j = nn[i];
+			if (nn[j] == i) {
+				if (i < j) {
+					Bin b; b.l = C[i].ref; b.r = C[j].ref; b.b = merge(C[i].b, C[j].b);
+					uint32_t cl = b.l < 0 ? 1 : bin[b.l].cnt, cr = b.r < 0 ? 1 : bin[b.r].cnt; b.cnt = cl + cr; b.cost = 0; b.leaf = false;
+					int id = (int)bin.size(); bin.push_back(b);
+					C2.push_back({ b.b, id });
+				}
+			} else C2.push_back(C[i]);
+		}
+		C.swap(C2); iters++;
+	}
+	root = C[0].ref;
+	fprintf(stderr, "ploc R=%d iterations %d nodes %zu\n", R, iters, bin.size());
+}
+
+
+// ---- binned SAH top-down over an arbitrary list of sorted indices (idx values index pbox/order)
+static int SAH_BINS = 32; static int SAH_LEAF = 1;
+static int sah_build(std::vector<int> &idx, int lo, int hi) {   // [lo,hi)
+	int n = hi - lo;
+	if (n == 1) return ~idx[lo];
+	Box cb; for (int k = 0; k < 3; k++) { cb.mn[k] = 1e30f; cb.mx[k] = -1e30f; }
+	Box nb = cb;
+	for (int i = lo; i < hi; i++) { const Box &b = pbox[idx[i]]; nb = merge(nb, b); for (int k = 0; k < 3; k++) { float c = b.mn[k] + b.mx[k]; cb.mn[k] = std::min(cb.mn[k], c); cb.mx[k] = std::max(cb.mx[k], c); } }
+	float bestc = INFINITY; int besta = -1, bestb = -1;
+	const int NB = SAH_BINS;
+	for (int a = 0; a < 3; a++) {
+		float ext = cb.mx[a] - cb.mn[a]; if (!(ext > 0)) continue;
+		std::vector<Box> bb(NB); std::vector<int> bc(NB, 0);
+		for (int b = 0; b < NB; b++) for (int k = 0; k < 3; k++) { bb[b].mn[k] = 1e30f; bb[b].mx[k] = -1e30f; }
+		float sc = NB / ext;
+		for (int i = lo; i < hi; i++) { const Box &b = pbox[idx[i]]; int bi = std::min(NB - 1, (int)(((b.mn[a] + b.mx[a]) - cb.mn[a]) * sc)); bb[bi] = merge(bb[bi], b); bc[bi]++; }
+		std::vector<float> ra(NB); std::vector<int> rc(NB);
+		Box acc; for (int k = 0; k < 3; k++) { acc.mn[k] = 1e30f; acc.mx[k] = -1e30f; } int cnt = 0;
+		for (int b = NB - 1; b >= 1; b--) { if (bc[b]) acc = merge(acc, bb[b]); cnt += bc[b]; ra[b] = cnt ? harea(acc) : 0; rc[b] = cnt; }
+		for (int k = 0; k < 3; k++) { acc.mn[k] = 1e30f; acc.mx[k] = -1e30f; } cnt = 0;
+		for (int b = 0; b < NB - 1; b++) { if (bc[b]) acc = merge(acc, bb[b]); cnt += bc[b]; if (cnt == 0 || rc[b + 1] == 0) continue; float c = harea(acc) * cnt + ra[b + 1] * rc[b + 1]; if (c < bestc) { bestc = c; besta = a; bestb = b; } }
+	}
+	int mid;
+	if (besta < 0) { mid = lo + n / 2; }
+	else {
+		float ext = cb.mx[besta] - cb.mn[besta], sc = NB / ext;
+		auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](int i) { const Box &b = pbox[i]; int bi = std::min(NB - 1, (int)(((b.mn[besta] + b.mx[besta]) - cb.mn[besta]) * sc)); return bi <= bestb; });
+		mid = (int)(it - idx.begin());
+		if (mid == lo || mid == hi) mid = lo + n / 2;
+	}
+	int id = (int)bin.size(); bin.push_back(Bin());
+	int l = sah_build(idx, lo, mid), r = sah_build(idx, mid, hi);
+	bin[id].l = l; bin[id].r = r;
+	return id;
+}
+// LBVH above, SAH rebuild of every maximal subtree with <= T prims
+static int HYB_T = 256;
+static int hyb_rec(int lo, int hi) {
+	if (hi - lo + 1 <= HYB_T) { std::vector<int> idx(hi - lo + 1); for (int i = lo; i <= hi; i++) idx[i - lo] = i; return sah_build(idx, 0, (int)idx.size()); }
+	int split; uint64_t a = keys[lo], b = keys[hi];
+	if (a == b) split = (lo + hi) / 2;
+	else { int pre = __builtin_clzll(a ^ b); int s = lo; int step = hi - lo; do { step = (step + 1) >> 1; int ns = s + step; if (ns < hi) { uint64_t k = keys[ns]; int d = (k == a) ? 64 : __builtin_clzll(a ^ k); if (d > pre) s = ns; } } while (step > 1); split = s; }
+	int id = (int)bin.size(); bin.push_back(Bin());
+	int l = hyb_rec(lo, split), r = hyb_rec(split + 1, hi);
+	bin[id].l = l; bin[id].r = r; return id;
+}
+
+// ---- SAH leaf decision (bottom-up): order-independent recursion
+static float CT = 1.0f, CN = 0.5f; static uint32_t MAXLEAF = 8;
+static float sah_rec(int id) {
+	Bin &n = bin[id];
+	float cost = 0;
+	for (int s = 0; s < 2; s++) { int ch = s ? n.r : n.l; if (ch < 0) cost += CT * harea(pbox[~ch]); else cost += sah_rec(ch); }
+	float area = harea(n.b);
+	float split = CN * area + cost;
+	float leaf = n.cnt <= MAXLEAF ? CT * (float)n.cnt * area : INFINITY;
+	n.leaf = leaf <= split; n.cost = std::min(leaf, split);
+	return n.cost;
+}
+
+// ---- BVH4
+static int WIDTH = 4; static int ORDERMODE = 0;
+struct W { Box b[8]; int ref[8]; /* >=0 wide idx; <0: leaf id ~k */ int n; };
+struct Leaf { std::vector<uint32_t> prims; };
+static std::vector<W> wide; static std::vector<Leaf> leaves;
+static int COLLAPSE_MODE = 0;   // 0 greedy largest area; 1 fixed two-level
+
+static void gather_prims(int ref, std::vector<uint32_t> &out) { if (ref < 0) { out.push_back(order[~ref]); return; } gather_prims(bin[ref].l, out); gather_prims(bin[ref].r, out); }
+
+static int make_leaf(int ref) { Leaf l; gather_prims(ref, l.prims); leaves.push_back(l); return ~(int)(leaves.size() - 1); }
+
+static Box ref_box(int ref) { return ref < 0 ? pbox[~ref] : bin[ref].b; }
+static bool ref_open(int ref) { return ref >= 0 && !bin[ref].leaf; }
+
+static void collapse() {
+	wide.clear(); leaves.clear();
+	std::vector<std::pair<int, int>> q;  // (bin, wide idx)
+	wide.push_back(W()); q.push_back({ root, 0 });
+	for (size_t qi = 0; qi < q.size(); qi++) {
+		int b = q[qi].first, wi = q[qi].second;
+		int c[8]; int nc;
+		if (bin[b].leaf) { c[0] = b; nc = 1; }
+		else {
+			c[0] = bin[b].l; c[1] = bin[b].r; nc = 2;
+			if (COLLAPSE_MODE == 0) {
+				for (int round = 0; round < WIDTH - 2; round++) {
+					int best = -1; float ba = 0;
+					for (int k = 0; k < nc; k++) if (ref_open(c[k])) { float a = harea(bin[c[k]].b); if (a > ba) { ba = a; best = k; } }
+					if (best < 0) break;
+					int o = c[best]; c[best] = bin[o].l; c[nc++] = bin[o].r;
+				}
+			} else {
+				int c2[4]; int n2 = 0;
+				for (int k = 0; k < 2; k++) { if (ref_open(c[k])) { c2[n2++] = bin[c[k]].l; c2[n2++] = bin[c[k]].r; } else c2[n2++] = c[k]; }
+				nc = n2; for (int k = 0; k < nc; k++) c[k] = c2[k];
+			}
+		}
+		W w; w.n = nc;
+		for (int k = 0; k < nc; k++) {
+			w.b[k] = ref_box(c[k]);
+			if (ref_open(c[k])) { int idx = (int)wide.size(); wide.push_back(W()); q.push_back({ c[k], idx }); w.ref[k] = idx; }
+			else w.ref[k] = make_leaf(c[k]);
+		}
+		wide[wi] = w;
+	}
+}
+
+// ---- traversal with counters
+struct Cnt { uint64_t nodes = 0, leaves = 0, tris = 0, hits = 0; };
+static bool tri_hit(const Ray &r, const float *p, double &t) {
+	double e1[3], e2[3], pv[3], tv[3], qv[3];
+	for (int k = 0; k < 3; k++) { e1[k] = (double)p[3 + k] - p[k]; e2[k] = (double)p[6 + k] - p[k]; }
+	pv[0] = r.d[1] * e2[2] - r.d[2] * e2[1]; pv[1] = r.d[2] * e2[0] - r.d[0] * e2[2]; pv[2] = r.d[0] * e2[1] - r.d[1] * e2[0];
+	double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+	if (det == 0) return false;
+	double inv = 1.0 / det;
+	for (int k = 0; k < 3; k++) tv[k] = (double)r.o[k] - p[k];
+	double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv; if (u < 0 || u > 1) return false;
+	qv[0] = tv[1] * e1[2] - tv[2] * e1[1]; qv[1] = tv[2] * e1[0] - tv[0] * e1[2]; qv[2] = tv[0] * e1[1] - tv[1] * e1[0];
+	double v = (r.d[0] * qv[0] + r.d[1] * qv[1] + r.d[2] * qv[2]) * inv; if (v < 0 || u + v > 1) return false;
+	t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+	return true;
+}
+
+static void trace(const Ray &r, Cnt &c) {
+	float best = r.tmax; bool hit = false;
+	float rd[3] = { 1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2] };
+	struct E { float t; int ref; } stack[256]; int sp = 0;
+	int top = 0; float topt = 0;
+	for (;;) {
+		if (top >= 0) {
+			const W &w = wide[top]; c.nodes++;
+			float key[8]; int ref[8]; int nh = 0;
+			for (int k = 0; k < w.n; k++) {
+				float tn = r.tmin, tf = best;
+				for (int a = 0; a < 3; a++) { float t0 = (w.b[k].mn[a] - r.o[a]) * rd[a], t1 = (w.b[k].mx[a] - r.o[a]) * rd[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+				if (tn <= tf) { key[nh] = tn; ref[nh] = w.ref[k]; nh++; }
+			}
+			if (ORDERMODE == 0) { for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); } }
+			else if (nh > 1) { int m = 0; for (int i = 1; i < nh; i++) if (key[i] < key[m]) m = i; std::swap(key[0], key[m]); std::swap(ref[0], ref[m]); }   // nearest first, rest in slot order
+			for (int i = nh - 1; i >= 1; i--) { stack[sp].t = key[i]; stack[sp].ref = ref[i]; sp++; }
+			if (nh) { top = ref[0]; topt = key[0]; continue; }
+		} else {
+			const Leaf &l = leaves[~top]; c.leaves++;
+			for (uint32_t p : l.prims) { c.tris++; double t; if (tri_hit(r, &tris[9 * (size_t)p], t) && t > r.tmin && t < best) { best = (float)t; hit = true; } }
+		}
+		bool got = false;
+		while (sp > 0) { sp--; if (stack[sp].t > best) continue; top = stack[sp].ref; got = true; break; }
+		if (!got) break;
+	}
+	(void)topt;
+	if (hit) c.hits++;
+}
+
+static std::vector<Ray> load_rays(const char *f) { FILE *fp = fopen(f, "rb"); fseek(fp, 0, SEEK_END); long s = ftell(fp); fseek(fp, 0, SEEK_SET); std::vector<Ray> r(s / 32); if (fread(r.data(), 32, r.size(), fp) != r.size()) abort(); fclose(fp); return r; }
+
+static double tree_sah() {
+	// SAH of the BVH4: sum over wide nodes of child areas (node test cost per child visited ~ area of the wide node's own box) -- report classic binary SAH instead
+	double ra = harea(bin[root].b), s = 0;
+	for (auto &w : wide) for (int k = 0; k < w.n; k++) s += harea(w.b[k]) / ra * (w.ref[k] >= 0 ? 1.0 : (double)leaves[~w.ref[k]].prims.size());
+	return s;
+}
+
+int main(int argc, char **argv) {
+	const char *trisf = "tris_1m.f32"; std::string builder = "lbvh"; int R = 16;
+	for (int i = 1; i < argc; i++) {
+		if (!strcmp(argv[i], "-b")) builder = argv[++i];
+		else if (!strcmp(argv[i], "-r")) R = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-cn")) CN = atof(argv[++i]);
+		else if (!strcmp(argv[i], "-ml")) MAXLEAF = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-cm")) COLLAPSE_MODE = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-t")) trisf = argv[++i];
+		else if (!strcmp(argv[i], "-T")) HYB_T = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-ks")) KEYSHIFT = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-w")) WIDTH = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-om")) ORDERMODE = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-bins")) SAH_BINS = atoi(argv[++i]);
+	}
+	{ FILE *fp = fopen(trisf, "rb"); fseek(fp, 0, SEEK_END); long s = ftell(fp); fseek(fp, 0, SEEK_SET); tris.resize(s / 4); if (fread(tris.data(), 4, tris.size(), fp) != tris.size()) abort(); fclose(fp); N = tris.size() / 9; }
+	morton_sort();
+	auto t0 = std::chrono::steady_clock::now();
+	if (builder == "lbvh") { bin.clear(); bin.reserve(N); root = lbvh_rec(0, (int)N - 1); refit_rec(root); }
+	else if (builder == "sah") { bin.clear(); bin.reserve(N); std::vector<int> idx(N); for (size_t i = 0; i < N; i++) idx[i] = (int)i; root = sah_build(idx, 0, (int)N); refit_rec(root); }
+	else if (builder == "hyb") { bin.clear(); bin.reserve(N); root = hyb_rec(0, (int)N - 1); refit_rec(root); }
+	else build_ploc(R);
+	double bt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	sah_rec(root);
+	collapse();
+	size_t ntl = 0; for (auto &l : leaves) ntl += l.prims.size();
+	printf("%s R=%d cn=%.2f ml=%u cm=%d: build %.2fs wide %zu leaves %zu (%.2f tris/leaf) sah4 %.2f\n", builder.c_str(), R, CN, MAXLEAF, COLLAPSE_MODE, bt, wide.size(), leaves.size(), (double)ntl / leaves.size(), tree_sah());
+	for (const char *rf : { "rays_coh.bin", "rays_inc.bin" }) {
+		auto rays = load_rays(rf); Cnt c;
+#pragma omp parallel
+		{ Cnt lc;
+#pragma omp for schedule(dynamic, 256)
+			for (long i = 0; i < (long)rays.size(); i++) trace(rays[i], lc);
+#pragma omp critical
+			{ c.nodes += lc.nodes; c.leaves += lc.leaves; c.tris += lc.tris; c.hits += lc.hits; } }
+		double n = (double)rays.size();
+		printf("  %-14s nodes %.2f leaves %.2f tris %.2f hit %.4f\n", rf, c.nodes / n, c.leaves / n, c.tris / n, c.hits / n);
+	}
+	return 0;
+}
