@@ -262,13 +262,15 @@ def main():
     packet_kernel = args.workload == "coherent" and not args.no_tiling and not args.no_packet and not DRY
     # SURVEY.md section 8d per unit the kernel actually fetches for: the packet kernel fetches a node / triangle ONCE
     # per 64-ray tile (scalar cache), the per-lane kernels once per ray.
-    per_ray_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * NODE_BYTES + ctr["triangles"] * TRI_BYTES
+    # the per-lane kernels read the 64-byte compressed nodes (DevNodeQ) unless RTK_AMD_QNODES=0, the packet kernel the 128-byte exact ones
+    lane_node_bytes = NODE_BYTES if os.environ.get("RTK_AMD_QNODES", "1") == "0" else 64
+    per_ray_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * (NODE_BYTES if packet_kernel else lane_node_bytes) + ctr["triangles"] * TRI_BYTES
     if packet_kernel:
         alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["wave_node_steps"] * NODE_BYTES + ctr["wave_triangle_steps"] * TRI_BYTES
         unit = "tile of 64 rays: each node (128 B) and triangle (48 B) is fetched once per tile through the scalar cache"
     else:
         alg_bytes = per_ray_bytes
-        unit = "ray: each lane fetches its own nodes (128 B) and triangles (48 B)"
+        unit = "ray: each lane fetches its own nodes (%d B) and triangles (48 B)" % lane_node_bytes
     sync()
 
     for k in range(args.warmup):
@@ -345,7 +347,8 @@ def main():
     mrays = total_rays / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    kernel_name = ("rtk_trace_packet_kernel<false>" if packet_kernel else "rtk_trace_kernel<%d, false, false>" % (1 if shadow else 0))
+    kernel_name = ("rtk_trace_packet_kernel<false>" if packet_kernel else
+                   "rtk_trace_kernel<%d, false, false, %s>" % (1 if shadow else 0, "true" if lane_node_bytes == 64 else "false"))
     out = {
         "metric": metric,
         "value": round(mrays, 2),

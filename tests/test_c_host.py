@@ -10,18 +10,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "examples", "host_demo")
 
 
+EXE2 = os.path.join(ROOT, "examples", "host_tasks")
+
+
 def _build():
     if not os.path.exists(os.path.join(ROOT, "rtk_amd", "librtk_amd.so")):
         import __graft_entry__
         __graft_entry__.build()
-    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "host_demo.c"), "-L" + os.path.join(ROOT, "rtk_amd"), "-lrtk_amd",
-                           "-Wl,-rpath," + os.path.join(ROOT, "rtk_amd"), "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", EXE])
+    for src, exe in (("host_demo.c", EXE), ("host_tasks.c", EXE2)):
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", src), "-L" + os.path.join(ROOT, "rtk_amd"), "-lrtk_amd", "-lpthread",
+                               "-Wl,-rpath," + os.path.join(ROOT, "rtk_amd"), "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe])
 
 
 def test_c_host_compiles_and_links():
     _build()
-    assert os.path.exists(EXE)
+    assert os.path.exists(EXE) and os.path.exists(EXE2)
+
+
+@pytest.mark.gpu
+def test_c_host_with_its_own_thread_pool_runs():
+    """examples/host_tasks.c: the task graph on four pthreads (CPU task builder), the blob traced on the GPU, the same
+    rays through the multi-GPU context on a device-built scene, and a host-callback filter."""
+    _build()
+    r = subprocess.run([EXE2, "100000", "65536"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 differences" in r.stdout and "tasks run on 4 threads" in r.stdout
 
 
 @pytest.mark.gpu
