@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--static", action="store_true", help="A/B: one fixed ray per lane instead of persistent refill")
     ap.add_argument("--no-tiling", action="store_true")
     ap.add_argument("--no-packet", action="store_true", help="A/B: image-shaped batch on the per-lane kernel")
-    ap.add_argument("--sort-rays", action="store_true", help="reorder the batch by origin cell + direction octant first (inside the timed step)")
+    ap.add_argument("--sort-rays", action="store_true", help="reorder the batch by origin cell first (inside the timed step); the default for --workload shadow")
+    ap.add_argument("--no-sort-rays", action="store_true", help="shadow workload: trace the batch in the order given")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--node-exit", type=int, default=0)
@@ -120,6 +121,10 @@ def main():
                          "multi-rank step loop / gather / timing / JSON plumbing in the CPU tests. Prints no perf claim.")
     args = ap.parse_args()
     DRY = args.dry_run_cpu
+    if args.workload == "shadow" and not args.no_sort_rays:
+        # 2^24 shadow rays in random order on a 10M-triangle scene are bound by lines through the fabric; the library's
+        # RTK_TRACE_SORT_RAYS pre-pass (origin-cell Morton order, part of every timed step) is worth +12 % there
+        args.sort_rays = True
 
     import torch
     import torch.distributed as dist
@@ -371,6 +376,7 @@ def main():
                    "hit_fraction": round(hit_frac, 4),
                    "gather": ("records to rank 0 over RCCL, overlapped with the next step's trace" if gather else None), "value_without_gather_mrays_s": round(n * world * args.steps / elapsed_no_gather / 1e6, 2) if elapsed_no_gather else None,
                    "launch": "static" if args.static else "persistent",
+                   "ray_order": "RTK_TRACE_SORT_RAYS: re-ordered by origin cell inside every timed step" if args.sort_rays else "as given",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -369,6 +369,9 @@ __global__ void k_emit_tris(const float *in_pos, const uint32_t *in_vidx, const 
 	t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2]; t.prim = g;
 	t.v1[0] = p[3]; t.v1[1] = p[4]; t.v1[2] = p[5]; t.flags = lo << 8;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
 	t.v2[0] = p[6]; t.v2[1] = p[7]; t.v2[2] = p[8]; t.spare = 0u;
+#if RTK_TRI_STRIDE == 64
+	t.pad[0] = t.pad[1] = t.pad[2] = t.pad[3] = 0u;
+#endif
 	tris[s] = t;
 	vertex_index[3 * (size_t)s + 0] = in_vidx[3 * (size_t)g + 0];
 	vertex_index[3 * (size_t)s + 1] = in_vidx[3 * (size_t)g + 1];

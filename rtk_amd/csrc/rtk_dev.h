@@ -51,12 +51,20 @@ struct DevNodeQ {
 };
 static_assert(sizeof(DevNodeQ) == 64, "quantised node must be half a 128 B line");
 
+// 48 B of payload at a stride of RTK_TRI_STRIDE bytes. At 48 a record straddles two 128-B lines three times in
+// eight (and two 64-B scalar-cache lines every other time); at 64 it never does, for 16 B more per triangle.
+#ifndef RTK_TRI_STRIDE
+#define RTK_TRI_STRIDE 48
+#endif
 struct DevTri {
 	float v0[3]; uint32_t prim;   // global primitive id
-	float v1[3]; uint32_t flags;  // RTK_TRI_LAST
+	float v1[3]; uint32_t flags;  // RTK_TRI_LAST | mesh index << 8
 	float v2[3]; uint32_t spare;  // first record of a leaf: number of triangles in the leaf
+#if RTK_TRI_STRIDE == 64
+	uint32_t pad[4];
+#endif
 };
-static_assert(sizeof(DevTri) == 48, "triangle record is 48 B");
+static_assert(sizeof(DevTri) == RTK_TRI_STRIDE, "triangle record stride");
 
 // Everything a kernel needs to know about a scene (passed by value).
 struct DevSceneView {

@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			uint32_t sn_prim = best_prim;
 			while (i < n) {
 				f32x4 A, B, C;
-				load_tri(tris, (slot0 + i) * 48u, A, B, C);
+				load_tri(tris, (slot0 + i) * (uint32_t)RTK_TRI_STRIDE, A, B, C);
 				if (COUNT && lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) w_tri_steps++;
 				if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
 				if ((i & 3u) == 0u) {
@@ -645,7 +645,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (!ds || (!d_rays && n) || ((any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
 	// the kernel addresses nodes and triangles as SGPR base + 32-bit byte offset
-	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * 48u > 0xffffff00ull) {
+	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * RTK_TRI_STRIDE > 0xffffff00ull) {
 		rtk_set_error("rtk_dev_trace: scene exceeds 4 GiB of nodes or triangles (%u nodes, %u triangles)", ds->view.num_nodes, ds->view.num_tris);
 		return RTK_AMD_ERR_UNSUPPORTED;
 	}

@@ -202,7 +202,7 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 {
 	i32x8 ta;
 	i32x4 tb;
-	s_load_tri(tris + (size_t)slot0 * 48u, ta, tb);
+	s_load_tri(tris + (size_t)slot0 * RTK_TRI_STRIDE, ta, tb);
 	const uint32_t n = (uint32_t)tb[3];                                // leaf size rides in the first record
 	for (uint32_t g = 0; g < n; g += 4u) {
 		const uint32_t m = n - g < 4u ? n - g : 4u;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 		const uint32_t sn_prim = L.prim;
 		bool zero_seen = false;
 		for (uint32_t j = 0; j < m; j++) {
-			if (g + j != 0u) s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
+			if (g + j != 0u) s_load_tri(tris + (size_t)(slot0 + g + j) * RTK_TRI_STRIDE, ta, tb);
 			if (COUNT && live) c_tris++;
 			if (COUNT && lane == 0) atomicAdd(counter + 8, 1ull);
 			if (force) pk_triangle<true, KZ>(L, live, ta, tb);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 			// an exact zero in a full group: those lanes redo the group in double (rtk.c:302-336)
 			if (redo) { L.t = sn_t; L.u = sn_u; L.v = sn_v; L.prim = sn_prim; }
 			for (uint32_t j = 0; j < m; j++) {
-				s_load_tri(tris + (size_t)(slot0 + g + j) * 48u, ta, tb);
+				s_load_tri(tris + (size_t)(slot0 + g + j) * RTK_TRI_STRIDE, ta, tb);
 				pk_triangle<true, KZ>(L, redo, ta, tb);
 			}
 		}
