@@ -276,6 +276,12 @@ def main():
     else:
         alg_bytes = per_ray_bytes
         unit = "ray: each lane fetches its own nodes (%d B) and triangles (48 B)" % lane_node_bytes
+        if args.sort_rays:
+            # the re-ordering pre-pass is inside the timed region: origin bounds (32 B read), keys (32 B read, 12 B written),
+            # two radix passes over (8 B key, 4 B index) pairs (8 B histogram read + 12 B read + 12 B written each)
+            alg_bytes += n * (32 + 44 + 2 * 32)
+            per_ray_bytes = alg_bytes
+            unit += "; plus the ray re-ordering pre-pass (140 B per ray), timed with the traversal"
     sync()
 
     for k in range(args.warmup):
@@ -386,7 +392,9 @@ def main():
                                      ("none: %s was measured on other kernel sources" % traffic_src if pj else None),
                      "unit_of_work": unit,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "kernel": kernel_name, "kernel_ms": round(k_ms, 4),
+                     "kernel": kernel_name if not args.sort_rays else kernel_name + " preceded by the re-ordering pre-pass (rtk_ray_bounds_kernel, "
+                               "rtk_ray_keys_kernel, 2 x k_sort_hist/k_scan_*/k_sort_scatter): kernel_ms is their sum per step",
+                     "kernel_ms": round(k_ms, 4),
                      "limiter": dict(limiter, note="issue-bound, not bandwidth-bound: VALU pipes busy this share of the launch at this "
                                      "lane utilisation (%s, %.1f GHz assumed); the BVH is served by L2/MALL" % (traffic_src, CLOCK_GHZ)) if limiter else None,
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),

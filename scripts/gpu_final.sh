@@ -18,3 +18,4 @@ r=d['roofline']; c=d.get('cpu_baseline',{})
 print('$wl', d['value'], 'Mrays/s kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'traffic', r['traffic'], 'limiter', r['limiter'] and {k:v for k,v in r['limiter'].items() if k!='note'}, 'build', d.get('build',{}).get('ms'))
 print('   cpu', c.get('value'), c.get('cores'), {k: (v if k!='mismatching_rays' else len(v)) for k,v in c.get('parity_vs_gpu_oracle_bvh',{}).items()}, c.get('parity_vs_gpu_same_bvh',{}).get('ids_exact'))"
 done
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_final.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke_final.log
