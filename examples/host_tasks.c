@@ -116,7 +116,10 @@ int main(int argc, char **argv)
 	if (rtk_mgpu_trace_rays(ctx, rays, num_rays, rec, NULL) != RTK_AMD_OK) { fprintf(stderr, "rtk_mgpu_trace_rays: %s\n", rtk_amd_last_error()); return 4; }
 	for (size_t i = 0; i < num_rays; i++) {
 		const int hit = rec[i].prim != RTK_PRIM_NONE;
-		if (hit != mask[i] || (hit && (rec[i].prim != hits[i].triangle_index || rec[i].t != hits[i].t))) bad++;
+		/* two different BVHs of the same triangles: same triangle, t within 1e-5 (a triangle's t can move by an ulp with
+		 * the leaf it sits in: rtk.c's group-of-four double-precision rule, rtk.c:302-336) */
+		const float dt = hit ? rec[i].t - hits[i].t : 0.0f;
+		if (hit != mask[i] || (hit && (rec[i].prim != hits[i].triangle_index || (dt < 0 ? -dt : dt) > 1e-5f * hits[i].t))) bad++;
 	}
 	printf("%d GPU(s): %zu rays, %zu hits, %d differences between the CPU-built and the device-built scene\n", rtk_mgpu_num_devices(ctx), num_rays, nhit, bad);
 	rtk_mgpu_destroy(ctx);
