@@ -386,17 +386,21 @@ def main():
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_unit": ("bytes per launch crossing the L2 -> fabric boundary, Infinity-Cache (MALL) hits INCLUDED: "
-                                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes, %s; not a pure HBM figure for a "
-                                      "131 MB BVH that fits the 256 MiB Infinity Cache" % traffic_src) if traffic else
+                     "traffic_unit": ("bytes per launch of the traversal kernel crossing the L2 -> fabric boundary, Infinity-Cache (MALL) hits "
+                                      "INCLUDED: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes, %s; the scene is %.0f MB (the MALL "
+                                      "holds 256 MiB), so this is %s" % (traffic_src, info.get("total_device_bytes", 0) / 1e6,
+                                      "not pure HBM traffic" if info.get("total_device_bytes", 0) < 256 * 2 ** 20 else "mostly HBM traffic")) if traffic else
                                      ("none: %s was measured on other kernel sources" % traffic_src if pj else None),
                      "unit_of_work": unit,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "kernel": kernel_name if not args.sort_rays else kernel_name + " preceded by the re-ordering pre-pass (rtk_ray_bounds_kernel, "
                                "rtk_ray_keys_kernel, 2 x k_sort_hist/k_scan_*/k_sort_scatter): kernel_ms is their sum per step",
                      "kernel_ms": round(k_ms, 4),
-                     "limiter": dict(limiter, note="issue-bound, not bandwidth-bound: VALU pipes busy this share of the launch at this "
-                                     "lane utilisation (%s, %.1f GHz assumed); the BVH is served by L2/MALL" % (traffic_src, CLOCK_GHZ)) if limiter else None,
+                     "limiter": dict(limiter, fabric_tb_s=round(traffic / pj["kernel_trace"]["average_ns"] / 1e3, 2) if traffic else None,
+                                     note=("VALU pipes busy `valu_busy` of the traversal kernel's time at `valu_lane_utilisation` "
+                                           "(SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * time * %.1f GHz), SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)), "
+                                           "`fabric_tb_s` = traffic / kernel time against ~6.3 TB/s achievable HBM and ~8.6 TB/s MALL gather rate; "
+                                           "counters from %s" % (CLOCK_GHZ, traffic_src))) if limiter else None,
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
                                         "triangles": round(ctr["triangles"] / n, 2)},
                      "wave_steps_per_64_rays": {"nodes": round(ctr["wave_node_steps"] * 64.0 / n, 1),
