@@ -486,11 +486,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 __device__ __forceinline__ uint32_t f2ord_(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float ord2f_(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-__global__ void rtk_ray_bounds_kernel(const rtk_ray *rays, unsigned long long n, uint32_t *bounds)
+// Origin bounds from every `stride`-th ray: the cells only have to spread the batch over the key range, outliers are
+// clamped into the border cells by the key kernel.
+__global__ void rtk_ray_bounds_kernel(const rtk_ray *rays, unsigned long long n, unsigned long long stride, uint32_t *bounds)
 {
 	__shared__ float s_mn[3][4], s_mx[3][4];
 	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
-	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+	for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k * stride < n; k += (unsigned long long)gridDim.x * blockDim.x) {
+		const unsigned long long i = k * stride;
 		const float4 r0 = *reinterpret_cast<const float4 *>(rays + i);
 		const float o[3] = { r0.x, r0.y, r0.z };
 		for (int a = 0; a < 3; a++) if (isfinite(o[a])) { mn[a] = fminf(mn[a], o[a]); mx[a] = fmaxf(mx[a], o[a]); }
@@ -515,7 +518,6 @@ __global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint3
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const float4 r0 = *reinterpret_cast<const float4 *>(rays + i);
-	const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rays + i) + 16);
 	const float o[3] = { r0.x, r0.y, r0.z };
 	const uint32_t cells = 1u << cell_bits;
 	uint32_t q[3];
@@ -531,8 +533,10 @@ __global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint3
 	uint32_t key = 0;
 	for (uint32_t b = 0; b < cell_bits; b++)
 		key |= (((q[0] >> b) & 1u) << (3u * b)) | (((q[1] >> b) & 1u) << (3u * b + 1u)) | (((q[2] >> b) & 1u) << (3u * b + 2u));
-	if (with_octant)
+	if (with_octant) {
+		const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rays + i) + 16);
 		key = (key << 3) | ((__float_as_uint(r0.w) >> 31) | ((__float_as_uint(r1.x) >> 31) << 1) | ((__float_as_uint(r1.y) >> 31) << 2));
+	}
 	keys[i] = key;
 	vals[i] = i;
 }
@@ -742,7 +746,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		uint32_t *bounds = vals_b + sc->sort_capacity, *scratch = bounds + 16;
 		static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
 		RTK_HIP_CHECK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream), RTK_AMD_ERR_HIP);
-		hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(256), 0, stream, d_rays, (unsigned long long)n, bounds);
+		hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 2)), dim3(256), 0, stream, d_rays, (unsigned long long)n,
+			(unsigned long long)(n >= (1u << 16) ? 61 : 1), bounds);
 		static const uint32_t cell_bits = getenv("RTK_AMD_SORT_CELL_BITS") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_CELL_BITS")) : 5u;
 		static const uint32_t with_octant = getenv("RTK_AMD_SORT_OCTANT") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_OCTANT")) : 0u;
 		hipLaunchKernelGGL(rtk_ray_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, bounds, keys_a, vals_a,
