@@ -351,8 +351,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 				}
 				// wave-level: which children does anybody enter
 				const bool e0 = pay[0] == pay[0], e1 = pay[1] == pay[1], e2 = pay[2] == pay[2], e3 = pay[3] == pay[3];
-				const bool a0 = __ballot(e0) != 0ull, a1 = __ballot(e1) != 0ull, a2 = __ballot(e2) != 0ull, a3 = __ballot(e3) != 0ull;
-				const uint32_t n_any = (a0 ? 1u : 0u) + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
+				// (a 4-bit set + s_bcnt1 on the scalar unit; summing four booleans went through VGPRs and readfirstlane: +2.3 %)
+				const uint32_t any_mask = (__ballot(e0) != 0ull ? 1u : 0u) | (__ballot(e1) != 0ull ? 2u : 0u) | (__ballot(e2) != 0ull ? 4u : 0u) | (__ballot(e3) != 0ull ? 8u : 0u);
+				const bool a0 = (any_mask & 1u) != 0u, a1 = (any_mask & 2u) != 0u, a2 = (any_mask & 4u) != 0u, a3 = (any_mask & 8u) != 0u;
+				const uint32_t n_any = (uint32_t)__builtin_popcount(any_mask);
 				uint32_t ref[4] = { (uint32_t)nd.ch[0], (uint32_t)nd.ch[1], (uint32_t)nd.ch[2], (uint32_t)nd.ch[3] };
 				if (n_any == 0u) {
 					pop = true;
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					top = a0 ? ref[0] : (a1 ? ref[1] : (a2 ? ref[2] : ref[3]));
 				} else if (n_any == 2u) {
 					// two children: pick them out (wave-uniform slot numbers), one comparison, one push
-					const uint32_t m = (a0 ? 1u : 0u) | (a1 ? 2u : 0u) | (a2 ? 4u : 0u) | (a3 ? 8u : 0u);
+					const uint32_t m = any_mask;
 					const uint32_t i0 = (uint32_t)__builtin_ctz(m), i1 = (uint32_t)__builtin_ctz(m & (m - 1u));
 					const float p0 = i0 == 0u ? pay[0] : (i0 == 1u ? pay[1] : pay[2]);            // i0 is 0, 1 or 2
 					const float p1 = i1 == 1u ? pay[1] : (i1 == 2u ? pay[2] : pay[3]);            // i1 is 1, 2 or 3
