@@ -229,8 +229,10 @@ int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_rays, const 
  * rtk_amd_forget_scene is called for it. Each calling thread uses its own stream and staging buffers. */
 size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask);
 /* Batch form of rtk_trace_ray_filter (rtk.h:130) with a host callback: per ray the closest candidate that
- * `filter` accepts. Every candidate of a ray is offered, in increasing (t, primitive id) order, until one is
- * accepted; the batch runs in rounds (one launch per round, not per candidate). */
+ * `filter` accepts. Every candidate of a ray is offered, in increasing (t, primitive id) order (equal-t ones
+ * included), until one is accepted. The batch runs in rounds: one launch collects the k closest candidates of
+ * every undecided ray (k = 4 for 16 384 rays ... 64 for a single ray); rays whose k candidates were all rejected
+ * continue after the last one in the next round. */
 size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask,
 	rtk_filter_fn *filter, void *filter_user);
 void rtk_amd_forget_scene(const rtk_scene *scene);

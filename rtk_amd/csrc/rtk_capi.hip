@@ -242,6 +242,11 @@ struct HostCtx {
 	rtk_hit *h_hits = nullptr, *d_hits = nullptr;
 	uint8_t *h_mask = nullptr, *d_mask = nullptr;
 	rtk_hit_record *h_after = nullptr, *d_after = nullptr;
+	// candidate lists for host-callback filters: CAND_SLOTS records in all, k = CAND_SLOTS / rays of them per ray
+	rtk_hit_record *h_cand = nullptr, *d_cand = nullptr;
+	rtk_hit *h_cand_hits = nullptr, *d_cand_hits = nullptr;
+	uint32_t *h_cand_count = nullptr, *d_cand_count = nullptr;
+	bool cand_ready = false;
 
 	void release()
 	{
@@ -249,7 +254,16 @@ struct HostCtx {
 		if (dev) (void)hipFree(dev);
 		pinned = dev = nullptr;
 		cap = 0;
+		if (h_cand) (void)hipHostFree(h_cand);
+		if (h_cand_hits) (void)hipHostFree(h_cand_hits);
+		if (h_cand_count) (void)hipHostFree(h_cand_count);
+		if (d_cand) (void)hipFree(d_cand);
+		if (d_cand_hits) (void)hipFree(d_cand_hits);
+		if (d_cand_count) (void)hipFree(d_cand_count);
+		h_cand = d_cand = nullptr; h_cand_hits = d_cand_hits = nullptr; h_cand_count = d_cand_count = nullptr;
+		cand_ready = false;
 	}
+	bool ensure_candidates();
 	~HostCtx()
 	{
 		release();
@@ -297,6 +311,23 @@ struct HostCtx {
 		return true;
 	}
 };
+
+const size_t CAND_SLOTS = (size_t)1 << 16;       // candidate records per round (4.4 MB of full hits)
+const size_t CAND_RAYS = (size_t)1 << 14;        // rays per round of a host-callback filter call: at least 4 candidates each
+
+bool HostCtx::ensure_candidates()
+{
+	if (cand_ready) return true;
+	const bool ok = hipHostMalloc((void **)&h_cand, CAND_SLOTS * sizeof(rtk_hit_record), hipHostMallocDefault) == hipSuccess &&
+		hipHostMalloc((void **)&h_cand_hits, CAND_SLOTS * sizeof(rtk_hit), hipHostMallocDefault) == hipSuccess &&
+		hipHostMalloc((void **)&h_cand_count, CAND_RAYS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+		hipMalloc((void **)&d_cand, CAND_SLOTS * sizeof(rtk_hit_record)) == hipSuccess &&
+		hipMalloc((void **)&d_cand_hits, CAND_SLOTS * sizeof(rtk_hit)) == hipSuccess &&
+		hipMalloc((void **)&d_cand_count, CAND_RAYS * sizeof(uint32_t)) == hipSuccess;
+	if (!ok) { rtk_set_error("rtk_trace_rays_filter: candidate buffers: %s", hipGetErrorString(hipGetLastError())); return false; }
+	cand_ready = true;
+	return true;
+}
 
 thread_local HostCtx t_ctx;
 
@@ -348,10 +379,11 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 // Batch form of rtk_trace_ray_filter (rtk.h:117, 130; a stub in the reference, rtk.c:579-582). Semantics:
 // for every ray the closest candidate hit the filter accepts. Candidates of a ray are offered in increasing
 // (t, primitive id) order -- every candidate, including several at one and the same t -- until one is
-// accepted or none is left. The callback runs on the host, so the batch goes in rounds: trace all undecided
-// rays, ask the filter about each one's candidate, and trace the rejected ones again restricted to what
-// comes after the rejected candidate. The number of launches is the longest rejection chain of any ray,
-// not the number of candidates.
+// accepted or none is left. The callback runs on the host, so the batch goes in rounds: a launch collects
+// the k closest candidates of every undecided ray (k = 65536 / rays in the round: 4 for a full round, up to 64
+// for a single ray), the callback is asked about them in order, and rays whose k candidates were all rejected
+// go into the next round restricted to what comes after the last one. Launches = rounds, not candidates: a
+// single ray needs one launch per 64 rejected candidates.
 extern "C" size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask,
 	rtk_filter_fn *filter, void *filter_user)
 {
@@ -361,34 +393,55 @@ extern "C" size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *r
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
 	HostCtx &c = t_ctx;
-	if (!c.ensure(n < HOST_CHUNK ? n : HOST_CHUNK)) return (size_t)-1;
+	if (!c.ensure(n < CAND_RAYS ? n : CAND_RAYS) || !c.ensure_candidates()) return (size_t)-1;
 	size_t count = 0;
 	std::vector<size_t> todo, next;
-	std::vector<rtk_ray> piece_rays;
 	std::vector<rtk_hit_record> after, next_after;
-	for (size_t at = 0; at < n; at += HOST_CHUNK) {
-		const size_t m = n - at < HOST_CHUNK ? n - at : HOST_CHUNK;
+	rtk_dev_filter f;
+	memset(&f, 0, sizeof(f));
+	f.struct_size = sizeof(f);
+	for (size_t at = 0; at < n; at += CAND_RAYS) {
+		const size_t m = n - at < CAND_RAYS ? n - at : CAND_RAYS;
 		todo.resize(m);
 		for (size_t i = 0; i < m; i++) todo[i] = at + i;
 		after.assign(m, rtk_hit_record{ 0.0f, 0.0f, 0.0f, RTK_PRIM_NONE });
 		if (hit_mask) memset(hit_mask + at, 0, m);
 		for (unsigned round = 0; !todo.empty(); round++) {
-			if (round > (1u << 16)) { rtk_set_error("rtk_trace_rays_filter: a ray had more than 65536 rejected candidates"); return (size_t)-1; }
-			piece_rays.resize(todo.size());
-			for (size_t k = 0; k < todo.size(); k++) { piece_rays[k] = rays[todo[k]]; c.h_after[k] = after[k]; }
-			if (!trace_piece(ds, c, piece_rays.data(), todo.size(), true, round > 0)) return (size_t)-1;
+			if (round > (1u << 16)) { rtk_set_error("rtk_trace_rays_filter: a ray had more than 2^18 rejected candidates"); return (size_t)-1; }
+			const size_t r = todo.size();
+			size_t k = CAND_SLOTS / r;
+			if (k > 64) k = 64;
+			for (size_t q = 0; q < r; q++) { c.h_rays[q] = rays[todo[q]]; c.h_after[q] = after[q]; }
+			bool ok = hipMemcpyAsync(c.d_rays, c.h_rays, r * sizeof(rtk_ray), hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+				hipMemcpyAsync(c.d_after, c.h_after, r * sizeof(rtk_hit_record), hipMemcpyHostToDevice, c.stream) == hipSuccess;
+			if (!ok) { rtk_set_error("rtk_trace_rays_filter: H2D copy failed"); return (size_t)-1; }
+			f.d_after = c.d_after;
+			// unused list slots stay "no primitive" so that the expand kernel leaves them alone
+			if (hipMemsetAsync(c.d_cand, 0xff, r * k * sizeof(rtk_hit_record), c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays_filter: memset failed"); return (size_t)-1; }
+			if (rtk_launch_trace(ds, c.d_rays, r, nullptr, nullptr, nullptr, c.stream, false, nullptr, &f, c.d_cand, c.d_cand_count, (uint32_t)k) != RTK_AMD_OK) return (size_t)-1;
+			if (rtk_launch_expand(ds, c.d_cand, r * k, c.d_cand_hits, nullptr, c.stream) != RTK_AMD_OK) return (size_t)-1;
+			ok = hipMemcpyAsync(c.h_cand, c.d_cand, r * k * sizeof(rtk_hit_record), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+				hipMemcpyAsync(c.h_cand_hits, c.d_cand_hits, r * k * sizeof(rtk_hit), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+				hipMemcpyAsync(c.h_cand_count, c.d_cand_count, r * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
+			if (!ok) { rtk_set_error("rtk_trace_rays_filter: D2H copy failed: %s", hipGetErrorString(hipGetLastError())); return (size_t)-1; }
+			if (rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return (size_t)-1;      // synchronises the stream
 			next.clear();
 			next_after.clear();
-			for (size_t k = 0; k < todo.size(); k++) {
-				if (!c.h_mask[k]) continue;                                   // no candidate left: a miss
-				const size_t i = todo[k];
-				if (filter(filter_user, &rays[i], &c.h_hits[k])) {
-					count++;
-					if (hits) hits[i] = c.h_hits[k];
-					if (hit_mask) hit_mask[i] = 1;
-				} else {
+			for (size_t q = 0; q < r; q++) {
+				const size_t i = todo[q];
+				const uint32_t have = c.h_cand_count[q];
+				bool accepted = false;
+				for (uint32_t j = 0; j < have && !accepted; j++) {
+					if (filter(filter_user, &rays[i], &c.h_cand_hits[q * k + j])) {
+						accepted = true;
+						count++;
+						if (hits) hits[i] = c.h_cand_hits[q * k + j];
+						if (hit_mask) hit_mask[i] = 1;
+					}
+				}
+				if (!accepted && have == k) {                                      // the list was full: there may be more behind it
 					next.push_back(i);
-					next_after.push_back(c.h_rec[k]);                          // continue after this (t, prim)
+					next_after.push_back(c.h_cand[q * k + k - 1]);
 				}
 			}
 			todo.swap(next);

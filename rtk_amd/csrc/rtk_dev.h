@@ -146,7 +146,7 @@ bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b
 // -- trace launches (rtk_trace.hip) --
 int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
-	const rtk_dev_filter *filter = nullptr);
+	const rtk_dev_filter *filter = nullptr, rtk_hit_record *d_cand = nullptr, uint32_t *d_cand_count = nullptr, uint32_t cand_k = 0);
 int rtk_trace_status(const rtk_dev_scene *ds, hipStream_t stream);
 void rtk_scratch_free(LaunchScratch *s);
 int rtk_launch_expand(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,

@@ -114,7 +114,7 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 #define PL_MIN_WAVES 4             // waves per SIMD the register allocator must leave room for
 #endif
 
-template <int MODE /*0 closest, 1 any*/, bool COUNT, bool FILT /*built-in candidate filters*/, bool QN /*64 B compressed nodes*/>
+template <int MODE /*0 closest, 1 any, 2 collect the k closest candidates*/, bool COUNT, bool FILT /*built-in candidate filters*/, bool QN /*64 B compressed nodes*/>
 __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(TraceParams p)
 {
 	__shared__ uint2 s_stack[WAVES_PER_BLOCK][LDS_STACK][64];
@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 	uint32_t onx = 0, ony = 0, onz = 0;     // byte offset of the NEAR plane row of each axis inside a node; far = the other row
 	float best_t = 0, best_u = 0, best_v = 0;
 	uint32_t best_prim = RTK_PRIM_NONE;
+	uint32_t cand_n = 0;                                  // MODE 2: candidates collected for this ray (<= p.cand_k), best_t = what the k-th one beats
 	float after_t = 0;                                    // FILT: candidates must come after (after_t, after_prim)
 	uint32_t after_prim = 0, skip_prim = RTK_PRIM_NONE;   // FILT: ... and must not be skip_prim
 	bool has_after = false;
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					}
 					top = 0u;  // root node
 					sp = 0u;
+					cand_n = 0u;
 					active = true;
 				}
 				w_next += take;
@@ -361,6 +363,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			if (COUNT) c_leaves++;
 			uint32_t i = 0, n = 1;
 			bool force = false, redo = false;
+			// MODE 2 cannot undo list insertions, so a full group is first scanned for exact zeros, then evaluated
+			bool scan = false, scanned = false, zero_in_group = false;
 			float sn_t = best_t, sn_u = best_u, sn_v = best_v;
 			uint32_t sn_prim = best_prim;
 			while (i < n) {
@@ -368,7 +372,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				load_tri(tris, (slot0 + i) * (uint32_t)RTK_TRI_STRIDE, A, B, C);
 				if (COUNT && lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) w_tri_steps++;
 				if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
-				if ((i & 3u) == 0u) {
+				if (MODE == 2 && (i & 3u) == 0u) {
+					if (scanned) scanned = false;                      // second pass over the group: `force` is decided
+					else { force = (n - i) < 4u; scan = !force; zero_in_group = false; }
+				} else if ((i & 3u) == 0u) {
 					if (redo) { force = true; redo = false; }
 					else {
 						if (MODE == 1 && best_prim != RTK_PRIM_NONE) break;   // any-hit: a whole group accepted something
@@ -393,11 +400,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				const float x2 = v2x + shx * v2z, y2 = v2y + shy * v2z, z2 = shz * v2z;
 				// edge functions (rtk.c:298-300)
 				float u, v, w;
+				if (MODE == 2 && scan) {
+					u = x1 * y2 - y1 * x2;
+					v = x2 * y0 - y2 * x0;
+					w = x0 * y1 - y0 * x1;
+					zero_in_group = zero_in_group || u == 0.0f || v == 0.0f || w == 0.0f;
+					if ((i & 3u) == 3u) { scan = false; scanned = true; force = zero_in_group; i &= ~3u; }   // rtk.c:306
+					else i++;
+					continue;
+				}
 				if (!force) {
 					u = x1 * y2 - y1 * x2;
 					v = x2 * y0 - y2 * x0;
 					w = x0 * y1 - y0 * x1;
-					if (u == 0.0f || v == 0.0f || w == 0.0f) {
+					if (MODE != 2 && (u == 0.0f || v == 0.0f || w == 0.0f)) {
 						// rtk.c:306: the whole group switches to double precision
 						best_t = sn_t; best_u = sn_u; best_v = sn_v; best_prim = sn_prim;
 						redo = true;
@@ -432,7 +448,29 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 						in_range = in_range && mesh < p.mesh_mask_bits && ((p.mesh_mask[mesh >> 5] >> (mesh & 31u)) & 1u);
 					}
 				}
-				if (MODE == 1) {
+				if (MODE == 2) {
+					// keep the k closest candidates of this ray, sorted by (t, prim), in the ray's slice of p.cand; once the
+					// list is full, best_t (the culling distance) is the last entry's t
+					rtk_hit_record *list = p.cand + (size_t)ray_index * p.cand_k;
+					if (in_range && cand_n == p.cand_k) {
+						const rtk_hit_record last = list[p.cand_k - 1u];
+						in_range = t < last.t || (t == last.t && prim < last.prim);
+					}
+					if (in_range) {
+						uint32_t j = cand_n < p.cand_k ? cand_n : p.cand_k - 1u;
+						while (j > 0u) {
+							const rtk_hit_record e = list[j - 1u];
+							if (e.t < t || (e.t == t && e.prim < prim)) break;
+							list[j] = e;
+							j--;
+						}
+						rtk_hit_record r;
+						r.t = t; r.u = u * rcp; r.v = v * rcp; r.prim = prim;
+						list[j] = r;
+						if (cand_n < p.cand_k) cand_n++;
+						if (cand_n == p.cand_k) best_t = list[p.cand_k - 1u].t;
+					}
+				} else if (MODE == 1) {
 					if (in_range && best_prim == RTK_PRIM_NONE) { best_prim = prim; best_t = t; }
 				} else {
 					// rtk.c:371 with the canonical tie rule: lowest primitive id among bit-equal t
@@ -452,7 +490,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 
 		// ---------------------------------------------------------------- retire
 		if (active && top == RTK_REF_NONE) {
-			if (MODE == 1) {
+			if (MODE == 2) {
+				p.cand_count[ray_index] = cand_n;
+			} else if (MODE == 1) {
 				p.occluded[ray_index] = best_prim != RTK_PRIM_NONE ? 1 : 0;
 			} else {
 				rtk_hit_record r;
@@ -592,10 +632,12 @@ trace_kernel_fn trace_variant(int v)
 	case 12: return rtk_trace_kernel<0, false, true, true>;
 	case 13: return rtk_trace_kernel<1, false, true, true>;
 	case 14: return rtk_trace_kernel<0, true, true, true>;
-	default: return rtk_trace_kernel<1, true, true, true>;
+	case 15: return rtk_trace_kernel<1, true, true, true>;
+	case 16: return rtk_trace_kernel<2, false, true, false>;      // collect the k closest candidates (host-callback filters)
+	default: return rtk_trace_kernel<2, false, true, true>;
 	}
 }
-enum { VARIANT_PACKET = 16, VARIANT_PACKET_COUNTED = 17, NUM_VARIANTS = 18 };
+enum { VARIANT_COLLECT = 16, VARIANT_PACKET = 18, VARIANT_PACKET_COUNTED = 19, NUM_VARIANTS = 20 };
 
 // resident workgroups per CU of each kernel variant, per device; filled on first use
 std::mutex g_occ_mutex;
@@ -643,10 +685,12 @@ void rtk_scratch_free(LaunchScratch *s)
 
 int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
-	const rtk_dev_filter *filter)
+	const rtk_dev_filter *filter, rtk_hit_record *d_cand, uint32_t *d_cand_count, uint32_t cand_k)
 {
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
-	if (!ds || (!d_rays && n) || ((any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
+	const bool collect = d_cand != nullptr;
+	if (collect && (!d_cand_count || cand_k == 0 || any_hit || counted)) { rtk_set_error("rtk_dev_trace: bad collect arguments"); return RTK_AMD_ERR_BAD_ARG; }
+	if (!ds || (!d_rays && n) || (!collect && (any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
 	// the kernel addresses nodes and triangles as SGPR base + 32-bit byte offset
 	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * RTK_TRI_STRIDE > 0xffffff00ull) {
@@ -659,6 +703,9 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.rays = d_rays;
 	p.hits = d_hits;
 	p.occluded = d_occluded;
+	p.cand = d_cand;
+	p.cand_count = d_cand_count;
+	p.cand_k = cand_k;
 	p.n = n;
 	p.dynamic = 1;
 	// Defaults from sweeps on MI355X (profiles/r01_sweep_opts*.log): leave the node
@@ -695,11 +742,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	}
 
 	// image-shaped closest-hit batches go to the wave-packet kernel (rtk_trace_packet.hip)
-	const bool packet = !any_hit && !filtered && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
+	const bool packet = !any_hit && !filtered && !collect && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
 	// per-lane kernels read the 64 B compressed nodes unless told otherwise (A/B, and tests that compare the two)
 	static const int qnodes_default = getenv("RTK_AMD_QNODES") ? atoi(getenv("RTK_AMD_QNODES")) : 1;
 	const bool qn = ds->view.qnodes != nullptr && qnodes_default != 0 && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_EXACT_NODES));
-	const int variant = packet ? (counted ? VARIANT_PACKET_COUNTED : VARIANT_PACKET)
+	const int variant = packet ? (counted ? VARIANT_PACKET_COUNTED : VARIANT_PACKET) : collect ? VARIANT_COLLECT + (qn ? 1 : 0)
 		: ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0) | (qn ? 8 : 0));
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;

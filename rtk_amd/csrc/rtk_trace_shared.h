@@ -30,6 +30,9 @@ struct TraceParams {
 	const uint32_t *ignore_prim;   // per ray: global primitive id that is never a candidate
 	const uint32_t *mesh_mask;     // bit m set = triangles of mesh m are candidates
 	uint32_t mesh_mask_bits;       // meshes covered by mesh_mask; meshes beyond it are not candidates
+	rtk_hit_record *cand;          // MODE 2: cand_k records per ray, the closest candidates in (t, prim) order
+	uint32_t *cand_count;          // MODE 2: how many of them are valid
+	uint32_t cand_k;
 	uint32_t tile_blocks;          // image batches: tiles are numbered block by block (8x8 tiles = 64x64 pixels), not row by row
 };
 
