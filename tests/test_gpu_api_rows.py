@@ -396,3 +396,42 @@ def test_single_process_multi_gpu_context_with_virtual_shards(api, oracle):
             assert d_rec[k].cpu().numpy().tobytes() == w.tobytes()
     finally:
         L.rtk_mgpu_destroy(m)
+
+
+def test_filter_rejection_chains_longer_than_one_launch_collects(api, oracle):
+    """A stack of 150 parallel triangles: a single ray collects 64 candidates per launch, a 16k-ray batch 4 per
+    launch; rejecting the first 100 candidates of every ray needs several rounds and still returns candidate 101,
+    offered in order, exactly once each; same answer as the oracle with the same predicate."""
+    zs = 1.0 + 0.01 * np.arange(150, dtype=np.float32)
+    tris = np.array([[[-1, -1, z], [3, -1, z], [-1, 3, z]] for z in zs], np.float32).reshape(-1, 3)
+    scene, keep = api.build_scene([dict(positions=tris)])
+    try:
+        ray = np.zeros(1, RAY_DTYPE)
+        ray["origin"] = (0.25, 0.25, 0)
+        ray["direction"] = (0, 0, 1)
+        ray["max_t"] = 100.0
+        offered = []
+
+        def pred(i, hit):
+            offered.append(int(hit["triangle_index"]))
+            return int(hit["triangle_index"]) >= 100
+        hits, mask = api.trace_rays_filter(scene, ray, pred)
+        assert mask[0] and hits["triangle_index"][0] == 100 and offered == list(range(101))
+        assert hits["t"][0] == zs[100]
+        # a batch: every ray rejects up to its own threshold
+        n = 16384
+        rays = np.zeros(n, RAY_DTYPE)
+        u = synth.u01(3, 0, 2 * n).reshape(n, 2)
+        rays["origin"][:, 0] = u[:, 0] * np.float32(0.5); rays["origin"][:, 1] = u[:, 1] * np.float32(0.5)
+        rays["direction"][:, 2] = 1
+        rays["max_t"] = 100.0
+        thr = (np.arange(n) * 7) % 160                      # some thresholds lie beyond the last triangle: those rays miss
+        hits, mask = api.trace_rays_filter(scene, rays, lambda i, hit: int(hit["triangle_index"]) >= thr[i])
+        assert (mask == (thr < 150)).all()
+        assert (hits["triangle_index"][mask] == thr[mask]).all()
+        blob = oracle.Blob(np.ascontiguousarray(api.scene_bytes(scene)))
+        oh, om = oracle.trace_filtered(blob, rays[:512], callback=lambda i, hit: int(hit["triangle_index"]) >= thr[i])
+        assert (om == mask[:512]).all() and (oh["triangle_index"][om] == hits["triangle_index"][:512][om]).all()
+        assert (oh["t"][om] == hits["t"][:512][om]).all()
+    finally:
+        api.free_scene(scene)
