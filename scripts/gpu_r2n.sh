@@ -1,0 +1,8 @@
+mkdir -p gpurun_out
+RTK_AMD_LIB=$PWD/build/libs/librtk_pkS.so timeout -k 10 600 python -m pytest tests/test_gpu_trace.py tests/test_gpu_fullsize.py -m gpu -q > gpurun_out/pytest_r2n.log 2>&1; rc=$?; tail -3 gpurun_out/pytest_r2n.log; echo "pytest(pkS) rc=$rc"
+run() { lib=$1; shift; RTK_AMD_LIB=$lib timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+r=d['roofline']
+print('lib=%s %s' % ('$lib'.split('/')[-1] or 'default', '$*'), d['value'], 'Mrays/s kernel_ms', r['kernel_ms'])" || echo "FAILED $lib $*"; }
+for rep in 1 2 3; do for lib in "" $PWD/build/libs/librtk_pkS.so; do run "$lib" --workload coherent; done; done 2>&1 | tee gpurun_out/ab_r2n.log
