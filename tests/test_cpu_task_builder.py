@@ -193,3 +193,29 @@ def test_tiny_scenes_through_the_task_graph(cpu_builder, oracle, n):
         return
     ohits, omask = oracle.trace_chain(oracle.leaf_chain_blobs(tris.reshape(-1, 3, 3)), rays)
     assert (mask == omask).all() and (hits["triangle_index"][mask] == ohits["triangle_index"][omask]).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_mixed_meshes_through_the_task_graph(cpu_builder, oracle, seed):
+    """Random scenes of several meshes with mixed index types (implicit, u16, u32), float32 / float64 positions,
+    strided buffers and callback meshes: the task-graph build, traversed by the oracle, gives the hits of the
+    REFERENCE-style leaf chain over the same triangles, with the caller's (mesh, triangle) identity and vertex indices."""
+    from tests.util import random_mixed_scene
+    L = cpu_builder
+    desc, keep, tris, mesh_index, tri_index, vidx = random_mixed_scene(seed)
+    first = Task()
+    b = L.rtk_start_build(C.byref(desc), C.byref(first))
+    assert b, api.last_error()
+    _run_serial(L, first, capacity=[3, 16, 256][seed % 3])
+    blob = _finish(L, oracle, b)
+    rc, counts = oracle.validate_blob(blob)
+    assert rc == 0 and counts["tris"] == len(tris)
+    rays = synth.rays_config1(4096, seed=seed + 20)
+    hits, mask = oracle.trace(blob, rays)
+    chain = oracle.leaf_chain_blobs(tris, mesh_index, tri_index, vidx)
+    ohits, omask = oracle.trace_chain(chain, rays)
+    assert (mask == omask).all() and mask.sum() > 100
+    for k in ("mesh_index", "triangle_index"):
+        assert (hits[k][mask] == ohits[k][omask]).all()
+    assert np.allclose(hits["t"][mask], ohits["t"][omask], rtol=1e-5, atol=0)
+    assert (np.sort(hits["vertex"]["index"][mask], axis=1) == np.sort(ohits["vertex"]["index"][omask], axis=1)).all()

@@ -347,3 +347,27 @@ def test_cpu_task_builder_blob_on_the_device(api, oracle, golden_dir):
         assert (m2 == mask[:4096]).all() and (h2["triangle_index"][m2] == hits["triangle_index"][:4096][m2]).all()
     finally:
         api.free_scene(scene)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_mixed_meshes_device_build(api, oracle, seed):
+    """The same random multi-mesh scenes (implicit / u16 / u32 indices, f32 / f64, strides, callbacks) through the DEVICE
+    builder: structurally valid, and the GPU's hits carry the caller's (mesh, triangle) identity and vertex indices --
+    equal to the reference-style leaf chain over the same triangles."""
+    from tests.util import random_mixed_scene
+    desc, keep, tris, mesh_index, tri_index, vidx = random_mixed_scene(seed)
+    h = api.lib().rtk_dev_scene_build(C.byref(desc))
+    assert h, api.last_error()
+    ds = api.DeviceScene(h, keepalive=keep)
+    ok, c = ds.validate()
+    assert ok and c["triangles_checked"] == len(tris) and c["loose_boxes"] == 0, c
+    rays = synth.rays_config1(8192, seed=seed + 20)
+    hits, mask, rec = ds.trace(rays)
+    ohits, omask = oracle.trace_chain(oracle.leaf_chain_blobs(tris, mesh_index, tri_index, vidx), rays)
+    assert (mask == omask).all() and mask.sum() > 100
+    for k in ("mesh_index", "triangle_index"):
+        assert (hits[k][mask] == ohits[k][omask]).all()
+    assert np.allclose(hits["t"][mask], ohits["t"][omask], rtol=1e-5, atol=0)
+    assert (np.sort(hits["vertex"]["index"][mask], axis=1) == np.sort(ohits["vertex"]["index"][omask], axis=1)).all()
+    base = ds.mesh_base()
+    assert (rec["prim"][mask] == base[hits["mesh_index"][mask].astype(np.int64)] + hits["triangle_index"][mask]).all()
