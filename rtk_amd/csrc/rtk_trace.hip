@@ -708,11 +708,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.cand_k = cand_k;
 	p.n = n;
 	p.dynamic = 1;
-	// Defaults from sweeps on MI355X (profiles/r01_sweep_opts*.log): leave the node
-	// loop once fewer than 24 lanes still descend; image-shaped (tiled, coherent) batches refill a
-	// wave only when it is empty, everything else as soon as 8 lanes are idle.
+	// Defaults from sweeps on MI355X (profiles/r01_sweep_opts*.log, r02_ab_r2o/p.log): leave the node
+	// loop once fewer than 32 lanes still descend (24 for image-shaped batches); image-shaped (tiled, coherent)
+	// batches refill a wave only when it is empty, everything else as soon as 8 lanes are idle.
 	p.refill_min = 8;
-	p.node_exit = 24;
+	p.node_exit = 32;
 	uint32_t blocks_per_cu = 0;
 	if (opts && opts->struct_size >= 16) {
 		if (opts->flags & RTK_TRACE_STATIC) p.dynamic = 0;
@@ -721,6 +721,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			p.image_w = opts->image_width;
 			p.image_h = opts->image_height;
 			p.refill_min = 64;
+			p.node_exit = 24;
 		}
 		if (opts->struct_size >= 24) {
 			if (opts->refill_min) p.refill_min = opts->refill_min > 64 ? 64 : opts->refill_min;
