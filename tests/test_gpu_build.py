@@ -371,3 +371,89 @@ def test_random_mixed_meshes_device_build(api, oracle, seed):
     assert (np.sort(hits["vertex"]["index"][mask], axis=1) == np.sort(ohits["vertex"]["index"][omask], axis=1)).all()
     base = ds.mesh_base()
     assert (rec["prim"][mask] == base[hits["mesh_index"][mask].astype(np.int64)] + hits["triangle_index"][mask]).all()
+
+
+def _adversarial_scenes():
+    rng = np.random.RandomState(5)
+    n = 40000
+    base = synth.triangle_soup(n, 0.05, seed=3).reshape(n, 3, 3)
+    scenes = {}
+    tiny = base * np.float32(1e-4)
+    tiny[0] = np.array([[900, 900, 900], [1000, 900, 900], [900, 1000, 950]], np.float32)      # one far, large triangle
+    scenes["tiny_cluster_plus_far_triangle"] = tiny
+    scenes["all_identical"] = np.repeat(base[:1], 5000, axis=0)                                  # every Morton key equal
+    line = base.copy(); line[:, :, 1] *= np.float32(1e-6); line[:, :, 2] *= np.float32(1e-6)      # a 1-D distribution along x
+    scenes["line_along_x"] = line
+    scenes["huge_coordinates"] = base * np.float32(1e6) + np.float32(3e7)
+    two = base.copy(); two[n // 2:] += np.float32(50.0)                                          # two clusters far apart
+    scenes["two_distant_clusters"] = two
+    flat = base.copy(); flat[:, :, 2] = np.float32(0.5)                                           # all triangles in one plane: flat boxes
+    scenes["coplanar"] = flat
+    g = 141                                                                                      # a floor: 2*141^2 non-overlapping triangles in z = 0.25
+    xs = (np.arange(g + 1, dtype=np.float32) / np.float32(g))
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    P = np.stack([X, Y, np.full_like(X, 0.25)], axis=-1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    scenes["flat_floor_grid"] = np.concatenate([np.stack([a, b, c], axis=2).reshape(-1, 3, 3), np.stack([a, c, d], axis=2).reshape(-1, 3, 3)])
+    return scenes
+
+
+@pytest.mark.parametrize("name", ["tiny_cluster_plus_far_triangle", "all_identical", "line_along_x", "huge_coordinates",
+                                  "two_distant_clusters", "coplanar", "flat_floor_grid"])
+def test_adversarial_distributions(api, oracle, name):
+    """Distributions that stress the Morton build (equal keys, truncated keys, degenerate extents, deep unbalanced
+    trees): the device BVH stays structurally valid and deterministic. Where boxes are resolvable in float, everything
+    coincides: device == rtk.c on the same BVH bit for bit (both node formats, both kernels) == brute force. Where they
+    are not (a 1e-4 cluster seen from 1e3 away, a line 1e-7 thin, overlapping triangles in a plane of zero thickness),
+    entry distances of boxes and hit distances of triangles are the same number up to rounding, so rtk.c's own culling
+    (rtk.c:432, 458-470) depends on the visit order among equal keys and ANY tight BVH can drop hits a brute-force pass
+    finds; there only what holds regardless is asserted (no traversal error, ids and t in range, barycentric u/v)."""
+    tris = np.ascontiguousarray(_adversarial_scenes()[name].reshape(-1, 3))
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert ok and c["loose_boxes"] == 0, (name, c)
+    assert api.DeviceScene.build([dict(positions=tris)]).validate()[1]["content_hash"] == c["content_hash"]
+    t3 = tris.reshape(-1, 3, 3)
+    lo, hi = t3.min(axis=(0, 1)).astype(np.float64), t3.max(axis=(0, 1)).astype(np.float64)
+    ext = np.maximum(hi - lo, 0.25 * (hi - lo).max())          # rays come from a cube around the scene, never from inside a flat one
+    n = 4096
+    u = synth.u01(9, 0, n * 6).reshape(n, 6).astype(np.float64)
+    rays = np.zeros(n, RAY_DTYPE)
+    org = lo - 0.5 * ext + 2.0 * ext * u[:, 0:3]
+    tgt = lo + ext * u[:, 3:6]
+    # half of the rays aim at triangle centroids so that thin / tiny scenes are hit at all
+    cent = t3.mean(axis=1).astype(np.float64)
+    tgt[::2] = cent[(np.arange(n // 2) * 7919) % len(cent)]
+    rays["origin"] = org.astype(np.float32)
+    rays["direction"] = (tgt - org).astype(np.float32)
+    rays["max_t"] = np.float32(4.0)
+    blob = _as_blob(oracle, ds.export_blob())
+    assert oracle.validate_blob(blob)[0] == 0
+    resolvable = name in ("huge_coordinates", "two_distant_clusters", "all_identical", "flat_floor_grid")
+    exact = ds.trace(rays, opts=api.make_opts(exact_nodes=True), full=False)
+    rec = ds.trace(rays, full=False)
+    em, qm = exact["prim"] != 0xFFFFFFFF, rec["prim"] != 0xFFFFFFFF
+    assert em.sum() > 50, (name, int(em.sum()))
+    ohits, omask = oracle.trace_chain(oracle.leaf_chain_blobs(t3), rays)          # brute force: rtk.c's triangle test on every triangle
+    t_chain = np.where(omask, ohits["t"], np.float32(np.inf))
+    if resolvable:
+        # (a) rtk.c on the same BVH, bit for bit: exact and compressed nodes, per-lane and packet kernel
+        oh, om = oracle.trace(blob, rays)
+        assert (em == om).all() and (exact["prim"][em] == oh["triangle_index"][om]).all(), name
+        assert (exact["t"][em] == oh["t"][om]).all() and (exact["u"][em] == oh["u"][om]).all() and (exact["v"][em] == oh["v"][om]).all(), name
+        assert rec.tobytes() == exact.tobytes()
+        if ds.info()["stack_entries"] <= 64:                          # else the per-lane kernel takes image-shaped batches too
+            assert ds.trace(rays, opts=api.make_opts(image=(64, 64)), full=False).tobytes() == exact.tobytes()
+    # (b) unresolvable scenes: hit/miss and the winner are rounding noise in rtk.c itself (and differ with the leaf grouping
+    #     through the double-precision group rule, rtk.c:302-336), so only what must hold regardless is asserted: no
+    #     traversal error, ids in range, t inside the ray's interval, u/v barycentric up to rounding
+    assert api.lib().rtk_dev_trace_status(ds.handle, None) == 0
+    for r_, m_ in ((exact, em), (rec, qm)):
+        assert (r_["prim"][m_] < len(t3)).all(), name
+        assert (r_["t"][m_] >= rays["min_t"][m_]).all() and (r_["t"][m_] <= rays["max_t"][m_]).all(), name
+        assert (r_["u"][m_] >= -1e-5).all() and (r_["v"][m_] >= -1e-5).all() and (r_["u"][m_] + r_["v"][m_] <= 1 + 1e-5).all(), name
+    if name in ("huge_coordinates", "two_distant_clusters", "flat_floor_grid"):
+        assert (omask == qm).all() and (ohits["triangle_index"][omask] == rec["prim"][qm]).all()
+        assert np.allclose(rec["t"][qm], ohits["t"][omask], rtol=1e-5, atol=0)
+    elif name == "all_identical":
+        assert (rec["prim"][qm] == 0).all()                                        # 5000 copies: the lowest id wins every tie
