@@ -27,6 +27,7 @@ __device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // All seven 16-B pieces of a node are requested back to back and waited for once. Left to
 // itself hipcc serialises them (load, wait, reuse the registers, load ...) to save VGPRs,
@@ -103,7 +104,11 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 		top = RTK_REF_NONE;                                                                                 \
 		while (sp > 0u) {                                                                                   \
 			--sp;                                                                                           \
-			const uint2 e_ = sp < LDS_STACK ? stk[sp][lane] : p.spill[(size_t)(sp - LDS_STACK) * p.spill_stride + glane]; \
+			uint2 e_ = stk[sp < LDS_STACK ? sp : LDS_STACK - 1u][lane];          /* always an LDS read (ds_read_b64), never a flat one */ \
+			if (sp >= LDS_STACK) {                       /* nontemporal: read once, and keeps hipcc from merging both into a flat load */ \
+				const unsigned long long w_ = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p.spill + (size_t)(sp - LDS_STACK) * p.spill_stride + glane)); \
+				e_ = make_uint2((uint32_t)w_, (uint32_t)(w_ >> 32));                                                \
+			}                                                                                                   \
 			if (__uint_as_float(e_.x) > best_t) continue;                                                   \
 			top = e_.y;                                                                                     \
 			break;                                                                                          \
@@ -285,11 +290,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				ref[0] = l3.x; ref[1] = l3.y; ref[2] = l3.z; ref[3] = l3.w;
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
-					const float ax = __builtin_fmaf(ubyte_f32(wnx, i), Sx, Anx), bx = __builtin_fmaf(ubyte_f32(wfx, i), Sx, Afx);
-					const float ay = __builtin_fmaf(ubyte_f32(wny, i), Sy, Any), by = __builtin_fmaf(ubyte_f32(wfy, i), Sy, Afy);
-					const float az = __builtin_fmaf(ubyte_f32(wnz, i), Sz, Anz), bz = __builtin_fmaf(ubyte_f32(wfz, i), Sz, Afz);
-					const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin_ray);
-					const float tf = fminf(fminf(fminf(bx, by), bz), best_t);
+					// near and far plane of one axis in one v_pk_fma_f32 (each half is the same single-rounded fma)
+					const f32x2 px = __builtin_elementwise_fma((f32x2){ ubyte_f32(wnx, i), ubyte_f32(wfx, i) }, (f32x2){ Sx, Sx }, (f32x2){ Anx, Afx });
+					const f32x2 py = __builtin_elementwise_fma((f32x2){ ubyte_f32(wny, i), ubyte_f32(wfy, i) }, (f32x2){ Sy, Sy }, (f32x2){ Any, Afy });
+					const f32x2 pz = __builtin_elementwise_fma((f32x2){ ubyte_f32(wnz, i), ubyte_f32(wfz, i) }, (f32x2){ Sz, Sz }, (f32x2){ Anz, Afz });
+					const float tn = fmaxf(fmaxf(fmaxf(px.x, py.x), pz.x), tmin_ray);
+					const float tf = fminf(fminf(fminf(px.y, py.y), pz.y), best_t);
 					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
 					key[i] = h ? tn : __builtin_inff();
 					nhit += h ? 1u : 0u;
@@ -552,6 +558,25 @@ __global__ void rtk_ray_bounds_kernel(const rtk_ray *rays, unsigned long long n,
 	}
 }
 
+__device__ __forceinline__ uint32_t morton_cells_(const uint32_t q[3], uint32_t cell_bits)
+{
+	// Morton-interleave the cell coordinates (x lowest) so that consecutive keys are neighbours in space
+	uint32_t key = 0;
+	for (uint32_t b = 0; b < cell_bits; b++)
+		key |= (((q[0] >> b) & 1u) << (3u * b)) | (((q[1] >> b) & 1u) << (3u * b + 1u)) | (((q[2] >> b) & 1u) << (3u * b + 2u));
+	return key;
+}
+
+__device__ __forceinline__ uint32_t cell_of_(float x, float lo, float hi, uint32_t cells)
+{
+	const float ext = hi - lo;
+	float t = ext > 0.0f ? (x - lo) / ext : 0.0f;
+	t = t >= 0.0f ? (t <= 1.0f ? t : 1.0f) : 0.0f;           // NaN -> 0
+	const uint32_t c = (uint32_t)(t * (float)cells);
+	return c > cells - 1u ? cells - 1u : c;
+}
+
+// Key = cell of the ray's origin inside the batch's (sampled) origin bounds.
 __global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals,
 	uint32_t cell_bits, uint32_t with_octant)
 {
@@ -559,23 +584,53 @@ __global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint3
 	if (i >= n) return;
 	const float4 r0 = *reinterpret_cast<const float4 *>(rays + i);
 	const float o[3] = { r0.x, r0.y, r0.z };
-	const uint32_t cells = 1u << cell_bits;
 	uint32_t q[3];
-	for (int a = 0; a < 3; a++) {
-		const float lo = ord2f_(bounds[a]), hi = ord2f_(bounds[3 + a]);
-		const float ext = hi - lo;
-		float t = ext > 0.0f ? (o[a] - lo) / ext : 0.0f;
-		t = t >= 0.0f ? (t <= 1.0f ? t : 1.0f) : 0.0f;           // NaN -> 0
-		const uint32_t c = (uint32_t)(t * (float)cells);
-		q[a] = c > cells - 1u ? cells - 1u : c;
-	}
-	// Morton-interleave the cell coordinates (x lowest) so that consecutive keys are neighbours in space
-	uint32_t key = 0;
-	for (uint32_t b = 0; b < cell_bits; b++)
-		key |= (((q[0] >> b) & 1u) << (3u * b)) | (((q[1] >> b) & 1u) << (3u * b + 1u)) | (((q[2] >> b) & 1u) << (3u * b + 2u));
+	for (int a = 0; a < 3; a++) q[a] = cell_of_(o[a], ord2f_(bounds[a]), ord2f_(bounds[3 + a]), 1u << cell_bits);
+	uint32_t key = morton_cells_(q, cell_bits);
 	if (with_octant) {
 		const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rays + i) + 16);
 		key = (key << 3) | ((__float_as_uint(r0.w) >> 31) | ((__float_as_uint(r1.x) >> 31) << 1) | ((__float_as_uint(r1.y) >> 31) << 2));
+	}
+	keys[i] = key;
+	vals[i] = i;
+}
+
+// Key = cell, inside the SCENE's bounds (union of the root's child boxes), of the point where the ray's [min_t, max_t]
+// interval enters those bounds: the origin itself for rays that start inside (shadow / bounce rays), the entry point for
+// rays that start outside (camera rays, config 3). That is where traversal starts doing work, so rays of one key share
+// the nodes and leaves they touch. Rays that miss the bounds get the largest key: they end at the root, together.
+__global__ void rtk_ray_entry_keys_kernel(const rtk_ray *rays, uint32_t n, const DevNode *root, unsigned long long *keys, uint32_t *vals,
+	uint32_t cell_bits, uint32_t with_octant)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (int k = 0; k < 4; k++) {
+		if (root->child[k] == RTK_REF_NONE) continue;
+		lo[0] = fminf(lo[0], root->bx[0][k]); hi[0] = fmaxf(hi[0], root->bx[1][k]);
+		lo[1] = fminf(lo[1], root->by[0][k]); hi[1] = fmaxf(hi[1], root->by[1][k]);
+		lo[2] = fminf(lo[2], root->bz[0][k]); hi[2] = fmaxf(hi[2], root->bz[1][k]);
+	}
+	const float4 r0 = *reinterpret_cast<const float4 *>(rays + i);
+	const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rays + i) + 16);
+	const float o[3] = { r0.x, r0.y, r0.z }, d[3] = { r0.w, r1.x, r1.y };
+	float tn = r1.z, tf = r1.w;
+	bool miss = false;
+	for (int a = 0; a < 3; a++) {
+		if (d[a] != 0.0f) {
+			const float t0 = (lo[a] - o[a]) / d[a], t1 = (hi[a] - o[a]) / d[a];
+			tn = fmaxf(tn, fminf(t0, t1));
+			tf = fminf(tf, fmaxf(t0, t1));
+		} else if (!(o[a] >= lo[a] && o[a] <= hi[a])) miss = true;
+	}
+	miss = miss || !(tn <= tf);                                   // NaN anywhere -> miss
+	const uint32_t key_bits = 3u * cell_bits + (with_octant ? 3u : 0u);
+	uint32_t key = (1u << key_bits) - 1u;
+	if (!miss) {
+		uint32_t q[3];
+		for (int a = 0; a < 3; a++) q[a] = cell_of_(o[a] + d[a] * tn, lo[a], hi[a], 1u << cell_bits);
+		key = morton_cells_(q, cell_bits);
+		if (with_octant) key = (key << 3) | ((__float_as_uint(d[0]) >> 31) | ((__float_as_uint(d[1]) >> 31) << 1) | ((__float_as_uint(d[2]) >> 31) << 2));
 	}
 	keys[i] = key;
 	vals[i] = i;
@@ -792,14 +847,20 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		unsigned long long *keys_a = (unsigned long long *)sc->d_sort, *keys_b = keys_a + sc->sort_capacity;
 		uint32_t *vals_a = (uint32_t *)(keys_b + sc->sort_capacity), *vals_b = vals_a + sc->sort_capacity;
 		uint32_t *bounds = vals_b + sc->sort_capacity, *scratch = bounds + 16;
-		static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-		RTK_HIP_CHECK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream), RTK_AMD_ERR_HIP);
-		hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 2)), dim3(256), 0, stream, d_rays, (unsigned long long)n,
-			(unsigned long long)(n >= (1u << 16) ? 61 : 1), bounds);
 		static const uint32_t cell_bits = getenv("RTK_AMD_SORT_CELL_BITS") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_CELL_BITS")) : 5u;
 		static const uint32_t with_octant = getenv("RTK_AMD_SORT_OCTANT") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_OCTANT")) : 0u;
-		hipLaunchKernelGGL(rtk_ray_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, bounds, keys_a, vals_a,
-			cell_bits, with_octant);
+		static const int entry_key = getenv("RTK_AMD_SORT_KEY") ? atoi(getenv("RTK_AMD_SORT_KEY")) : 1;   // 0: origin cell in the batch's origin bounds
+		if (entry_key && ds->view.num_nodes) {
+			hipLaunchKernelGGL(rtk_ray_entry_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, ds->view.nodes, keys_a, vals_a,
+				cell_bits, with_octant);
+		} else {
+			static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+			RTK_HIP_CHECK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream), RTK_AMD_ERR_HIP);
+			hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 2)), dim3(256), 0, stream, d_rays, (unsigned long long)n,
+				(unsigned long long)(n >= (1u << 16) ? 61 : 1), bounds);
+			hipLaunchKernelGGL(rtk_ray_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, bounds, keys_a, vals_a,
+				cell_bits, with_octant);
+		}
 		const bool in_b = rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n32, 3u * cell_bits + (with_octant ? 3u : 0u), scratch, stream);
 		p.perm = in_b ? vals_b : vals_a;
 	}
