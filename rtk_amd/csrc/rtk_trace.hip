@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 
 	for (;;) {
 		// ---------------------------------------------------------------- refill
-		const unsigned long long idle = __ballot(!active);
+		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
 		const uint32_t n_idle = (uint32_t)__popcll(idle);
 		if (n_idle == 64u || (n_idle >= p.refill_min && !(pool_empty && w_next >= w_end))) {
 			if (w_next >= w_end && !pool_empty) {
@@ -245,8 +245,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				}
 				w_next += take;
 			}
-			wave_fast = __ballot(active && special) == 0ull;
-			if (__ballot(active) == 0ull) {
+			wave_fast = __builtin_amdgcn_ballot_w64(active && special) == 0ull;
+			if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
 				if (pool_empty && w_next >= w_end) break;
 				continue;
 			}
@@ -257,9 +257,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			// Lanes that reached a leaf wait here for the others. When only a few lanes are
 			// still descending and leaves are waiting, go and do the leaves first.
 			const bool want_node = active && (int32_t)top >= 0;
-			const unsigned long long m_node = __ballot(want_node);
+			const unsigned long long m_node = __builtin_amdgcn_ballot_w64(want_node);
 			if (m_node == 0ull) break;
-			if ((uint32_t)__popcll(m_node) < p.node_exit && __ballot(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
+			if ((uint32_t)__popcll(m_node) < p.node_exit && __builtin_amdgcn_ballot_w64(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
 			if (COUNT) w_node_steps++;
 			if (!want_node) continue;
 			uint32_t ref[4];
@@ -346,11 +346,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				RTK_POP();
 			} else {
 				top = ref[0];
+				const uint32_t np = nhit - 1u;              // sorted slots np..1 go on the stack, far to near
+				if (sp + 3u <= LDS_STACK) {
+					// Branch-free: rows sp..sp+2 all exist. Slot i <= np goes to row sp+np-i; the others (misses) are
+					// written too, to the distinct rows sp+np..sp+2 above the new top, where garbage is harmless.
 #pragma unroll
-				for (int i = 3; i >= 1; i--) {
-					if (nhit > (uint32_t)i) {
-						const uint2 e = make_uint2(__float_as_uint(key[i]), ref[i]);
-						RTK_PUSH(e);
+					for (int i = 1; i <= 3; i++) {
+						const uint32_t row = sp + np - (uint32_t)i + ((uint32_t)i > np ? 3u : 0u);
+						stk[row][lane] = make_uint2(__float_as_uint(key[i]), ref[i]);
+					}
+					sp += np;
+				} else {
+#pragma unroll
+					for (int i = 3; i >= 1; i--) {
+						if (nhit > (uint32_t)i) {
+							const uint2 e = make_uint2(__float_as_uint(key[i]), ref[i]);
+							RTK_PUSH(e);
+						}
 					}
 				}
 			}
@@ -376,7 +388,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			while (i < n) {
 				f32x4 A, B, C;
 				load_tri(tris, (slot0 + i) * (uint32_t)RTK_TRI_STRIDE, A, B, C);
-				if (COUNT && lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) w_tri_steps++;
+				if (COUNT && lane == (uint32_t)__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1u) w_tri_steps++;
 				if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
 				if (MODE == 2 && (i & 3u) == 0u) {
 					if (scanned) scanned = false;                      // second pass over the group: `force` is decided
