@@ -97,23 +97,26 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 		} else p.counter[RTK_ERROR_WORD] = 1ull;                                                            \
 	} while (0)
 
-// Next node from the stack, skipping entries that start behind the current hit (rtk.c:432; canonical ties: an
-// entry AT the hit distance may still hold an equal-t candidate with a lower id). top = NONE when it is empty.
+// Next node from the stack: ONE entry per call. An entry that starts behind the current hit (rtk.c:432; canonical ties:
+// an entry AT the hit distance may still hold an equal-t candidate with a lower id) leaves top = RTK_REF_RETRY and the
+// lane pops again at the head of the next node-loop trip, beside the other lanes' node steps. A `while` here cost 5.4
+// wave-level trips per step on incoherent rays (7 of a ray's ~27 pops are culled, and the wave waits for its unluckiest
+// lane): as many instructions as the box tests. top = NONE when the stack is empty.
+#define RTK_REF_RETRY 0xfffffffeu
 #define RTK_POP()                                                                                           \
 	do {                                                                                                    \
-		top = RTK_REF_NONE;                                                                                 \
-		while (sp > 0u) {                                                                                   \
+		if (sp == 0u) top = RTK_REF_NONE;                                                                   \
+		else {                                                                                              \
 			--sp;                                                                                           \
 			uint2 e_ = stk[sp < LDS_STACK ? sp : LDS_STACK - 1u][lane];          /* always an LDS read (ds_read_b64), never a flat one */ \
 			if (sp >= LDS_STACK) {                       /* nontemporal: read once, and keeps hipcc from merging both into a flat load */ \
 				const unsigned long long w_ = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p.spill + (size_t)(sp - LDS_STACK) * p.spill_stride + glane)); \
 				e_ = make_uint2((uint32_t)w_, (uint32_t)(w_ >> 32));                                                \
 			}                                                                                                   \
-			if (__uint_as_float(e_.x) > best_t) continue;                                                   \
-			top = e_.y;                                                                                     \
-			break;                                                                                          \
+			top = __uint_as_float(e_.x) > best_t ? RTK_REF_RETRY : e_.y;                                    \
 		}                                                                                                   \
 	} while (0)
+#define RTK_IS_LEAF(top_) ((top_) < RTK_REF_RETRY && (int32_t)(top_) < 0)
 
 #ifndef PL_MIN_WAVES
 #define PL_MIN_WAVES 4             // waves per SIMD the register allocator must leave room for
@@ -256,10 +259,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 		for (;;) {
 			// Lanes that reached a leaf wait here for the others. When only a few lanes are
 			// still descending and leaves are waiting, go and do the leaves first.
+			const bool retry = active && top == RTK_REF_RETRY;
+			if (retry) RTK_POP();
 			const bool want_node = active && (int32_t)top >= 0;
 			const unsigned long long m_node = __builtin_amdgcn_ballot_w64(want_node);
-			if (m_node == 0ull) break;
-			if ((uint32_t)__popcll(m_node) < p.node_exit && __builtin_amdgcn_ballot_w64(active && top != RTK_REF_NONE && (int32_t)top < 0) != 0ull) break;
+			if (m_node == 0ull) {
+				if (__builtin_amdgcn_ballot_w64(active && top == RTK_REF_RETRY) != 0ull) continue;   // somebody is still popping
+				break;
+			}
+			// (lanes still popping are not counted as descending: counting them was 1 % slower)
+			if ((uint32_t)__popcll(m_node) < p.node_exit && __builtin_amdgcn_ballot_w64(active && RTK_IS_LEAF(top)) != 0ull) break;
 			if (COUNT) w_node_steps++;
 			if (!want_node) continue;
 			uint32_t ref[4];
@@ -376,7 +385,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 		// known up front; a zero inside a full group is rare, so the group is simply
 		// redone from a snapshot of the best hit. This keeps t/u/v bit-identical to
 		// rtk.c traversing the same leaves.
-		if (active && top != RTK_REF_NONE && (int32_t)top < 0) {
+		if (active && RTK_IS_LEAF(top)) {
 			const uint32_t slot0 = top & 0x7fffffffu;
 			if (COUNT) c_leaves++;
 			uint32_t i = 0, n = 1;
