@@ -54,8 +54,9 @@ struct BuildParams {
 // ---------------------------------------------------------------------------------- 1 ingest
 
 // IDX: 0 implicit (3i,3i+1,3i+2), 1 u16, 2 u32 (rtk.c:1028-1070). F64: positions are doubles (rtk.c:1098, B20).
-// Compile-time variants on purpose: the run-time if/else-if/else form of this kernel was
-// miscompiled by hipcc 7.2 for gfx950 (the u32 arm lost the initialisation of the output index).
+// Compile-time variants: the index and position formats are per mesh, so each launch is one straight-line path
+// (a run-time if/else-if/else form of this kernel faulted in round 1; its cause was never reduced, so nothing
+// is claimed about it -- every arm, RTK_TYPE_DEFAULT indices included, is covered by tests/test_gpu_build.py).
 template <int IDX, bool F64>
 __global__ void k_ingest(const char *pos, unsigned long long pos_stride, const char *idx,
 	unsigned long long idx_stride, uint32_t ntris, uint32_t base, float *in_pos, uint32_t *in_vidx)
@@ -569,18 +570,26 @@ __global__ void k_refit_top(const DevTri *tris, int n, const int2 *lr, const int
 // an inner node (the reference collapses exactly two binary levels, rtk.c:1572-1592; the greedy rule
 // costs 2 % fewer node visits on the benchmark scene). Wide-node numbers come from prefix sums, not from
 // an atomic counter, so the node array is the same for every build of the same input:
-//   k_collapse_decide  per job: the (up to four) children and how many of them are wide nodes themselves
-//   k_collapse_scan    exclusive scan of the per-256-job sums (one workgroup)
-//   k_collapse_emit    per job: write the 128 B node; its inner children become the next level's jobs
-// The level sizes live in device memory (LevelState); the host only reads them back every few levels.
+//   k_collapse_decide  per job: the (up to four) children and how many of them are wide nodes themselves;
+//                      per 256 jobs their sum
+//   k_collapse_emit    per job: write the 128 B node; its inner children become the next level's jobs. The
+//                      offset of a block of 256 jobs is the sum of the block sums before it, which every
+//                      block adds up for itself (a separate scan launch per level cost more than the reads)
+//   k_collapse_small   levels of at most 1024 jobs -- the top six and the last few -- decide, scan and emit
+//                      in ONE workgroup, several levels per launch
+// The level bookkeeping lives in device memory: launch number `step` reads ring entry step and writes entry
+// step+1, so nothing a running kernel reads is written by it. The host reads it back once per round.
 #define COLLAPSE_BLOCK 256
+#define COLLAPSE_SMALL 1024
+#define COLLAPSE_RING 64
 
 struct LevelState {
-	uint32_t count[2];        // jobs of level L at [L & 1]
-	uint32_t base[2];         // wide-node index of the first job of level L at [L & 1]
+	uint32_t count;           // jobs of this level
+	uint32_t base;            // wide-node index of its first job
+	uint32_t level;
 	uint32_t total_nodes;
 	uint32_t depth;
-	uint32_t pad[2];
+	uint32_t pad[3];
 };
 
 struct Cand {
@@ -600,46 +609,114 @@ __device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin)
 	return c;
 }
 
-__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *jobs, const LevelState *st, uint32_t level, const int2 *lr,
-	const BinNode *bin, int4 *dec, uint32_t *info, uint32_t *block_sums)
+// The children of the wide node made from binary node b; returns how many of them are wide nodes themselves.
+__device__ __forceinline__ uint32_t collapse_decide_one(int b, const int2 *lr, const BinNode *bin, int4 &dec, uint32_t &info)
+{
+	Cand c[4];
+	int nc;
+	if (bin[b].cnt_flag & 0x80000000u) {
+		// the whole (sub)tree is one leaf: only the root of a tiny scene
+		c[0].ref = b; c[0].area = -1.0f;
+		nc = 1;
+	} else {
+		const int2 ch = lr[b];
+		c[0] = make_cand(ch.x, bin);
+		c[1] = make_cand(ch.y, bin);
+		nc = 2;
+		for (int round = 0; round < 2; round++) {
+			int best = -1;
+			float best_area = 0.0f;
+			for (int k = 0; k < nc; k++) if (c[k].area > best_area) { best_area = c[k].area; best = k; }
+			if (best < 0) break;
+			const int2 o = lr[c[best].ref];
+			c[best] = make_cand(o.x, bin);
+			c[nc] = make_cand(o.y, bin);
+			nc++;
+		}
+	}
+	uint32_t mask = 0, n_inner = 0;
+	int r[4] = { 0, 0, 0, 0 };
+	for (int k = 0; k < nc; k++) {
+		r[k] = c[k].ref;
+		if (c[k].area > 0.0f) { mask |= 1u << k; n_inner++; }
+	}
+	dec = make_int4(r[0], r[1], r[2], r[3]);
+	info = (uint32_t)nc | (mask << 4) | (n_inner << 8);
+	return n_inner;
+}
+
+// Wide node `node_index` from its decision; its inner children get the numbers next_base + off, off + 1, ...
+__device__ __forceinline__ void collapse_emit_one(uint32_t node_index, uint32_t next_base, uint32_t off, const int4 d, uint32_t inf,
+	const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, int *next_jobs)
+{
+	const int ref[4] = { d.x, d.y, d.z, d.w };
+	const uint32_t nc = inf & 15u, mask = (inf >> 4) & 15u;
+	DevNode out;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		out.pad[k] = 0;
+		if ((uint32_t)k >= nc) {
+			out.bx[0][k] = out.by[0][k] = out.bz[0][k] = +1.0f;   // inverted = never hit (rtk.c:1612-1620)
+			out.bx[1][k] = out.by[1][k] = out.bz[1][k] = -1.0f;
+			out.child[k] = RTK_REF_NONE;
+			continue;
+		}
+		float mn[3], mx[3];
+		const int r = ref[k];
+		if (r < 0) {
+			const uint32_t sl = (uint32_t)~r;
+			tri_box(tris, sl, mn, mx);
+			tris[sl].spare = 1u;
+			tris[sl].flags |= RTK_TRI_LAST;
+			out.child[k] = RTK_REF_LEAF | sl;
+		} else {
+			const BinNode b = bin[r];
+			mn[0] = b.mn[0]; mn[1] = b.mn[1]; mn[2] = b.mn[2];
+			mx[0] = b.mx[0]; mx[1] = b.mx[1]; mx[2] = b.mx[2];
+			if (mask & (1u << k)) {
+				next_jobs[off] = r;
+				out.child[k] = next_base + off;
+				off++;
+			} else {
+				const uint2 rg = range[r];
+				tris[rg.x].spare = rg.y - rg.x + 1u;
+				tris[rg.y].flags |= RTK_TRI_LAST;
+				out.child[k] = RTK_REF_LEAF | rg.x;
+			}
+		}
+		out.bx[0][k] = mn[0]; out.bx[1][k] = mx[0];
+		out.by[0][k] = mn[1]; out.by[1][k] = mx[1];
+		out.bz[0][k] = mn[2]; out.bz[1][k] = mx[2];
+	}
+	nodes[node_index] = out;
+}
+
+__device__ __forceinline__ LevelState next_level(const LevelState &L, uint32_t next_count)
+{
+	LevelState N = L;
+	N.count = next_count;
+	N.base = L.base + L.count;
+	N.level = L.level + 1u;
+	if (L.count) { N.total_nodes = L.base + L.count; N.depth = L.level + 1u; }
+	return N;
+}
+
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *jobs_a, const int *jobs_b, const LevelState *ring, uint32_t step,
+	const int2 *lr, const BinNode *bin, int4 *dec, uint32_t *info, uint32_t *block_sums)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
-	const uint32_t count = st->count[level & 1u];
+	const LevelState L = ring[step % COLLAPSE_RING];
+	const int *jobs = (L.level & 1u) ? jobs_b : jobs_a;
+	const uint32_t count = L.count;
 	for (uint32_t vb = blockIdx.x; vb * COLLAPSE_BLOCK < count; vb += gridDim.x) {
 		const uint32_t j = vb * COLLAPSE_BLOCK + threadIdx.x;
 		uint32_t n_inner = 0;
 		if (j < count) {
-			const int b = jobs[j];
-			Cand c[4];
-			int nc;
-			if (bin[b].cnt_flag & 0x80000000u) {
-				// the whole (sub)tree is one leaf: only the root of a tiny scene
-				c[0].ref = b; c[0].area = -1.0f;
-				nc = 1;
-			} else {
-				const int2 ch = lr[b];
-				c[0] = make_cand(ch.x, bin);
-				c[1] = make_cand(ch.y, bin);
-				nc = 2;
-				for (int round = 0; round < 2; round++) {
-					int best = -1;
-					float best_area = 0.0f;
-					for (int k = 0; k < nc; k++) if (c[k].area > best_area) { best_area = c[k].area; best = k; }
-					if (best < 0) break;
-					const int2 o = lr[c[best].ref];
-					c[best] = make_cand(o.x, bin);
-					c[nc] = make_cand(o.y, bin);
-					nc++;
-				}
-			}
-			uint32_t mask = 0;
-			int r[4] = { 0, 0, 0, 0 };
-			for (int k = 0; k < nc; k++) {
-				r[k] = c[k].ref;
-				if (c[k].area > 0.0f) { mask |= 1u << k; n_inner++; }
-			}
-			dec[j] = make_int4(r[0], r[1], r[2], r[3]);
-			info[j] = (uint32_t)nc | (mask << 4) | (n_inner << 8);
+			int4 d;
+			uint32_t inf;
+			n_inner = collapse_decide_one(jobs[j], lr, bin, d, inf);
+			dec[j] = d;
+			info[j] = inf;
 		}
 		uint32_t sum = n_inner;
 		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -654,102 +731,80 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *j
 	}
 }
 
-// One workgroup: exclusive scan of the block sums of level `level`, and the bookkeeping of the next level.
-__global__ void __launch_bounds__(1024) k_collapse_scan(uint32_t *block_sums, LevelState *st, uint32_t level)
+// Sum of a[lo..hi) for the whole workgroup (COLLAPSE_BLOCK threads).
+__device__ __forceinline__ uint32_t block_range_sum(const uint32_t *a, uint32_t lo, uint32_t hi, uint32_t *s_w)
 {
-	__shared__ uint32_t s_wave[16];
-	__shared__ uint32_t s_carry;
-	const uint32_t count = st->count[level & 1u];
-	const uint32_t nb = (count + COLLAPSE_BLOCK - 1u) / COLLAPSE_BLOCK;
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0) s_carry = 0;
+	uint32_t t = 0;
+	for (uint32_t i = lo + threadIdx.x; i < hi; i += COLLAPSE_BLOCK) t += a[i];
+	for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+	__syncthreads();                                    // s_w may still be read from the previous use
+	if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = t;
 	__syncthreads();
-	for (uint32_t base = 0; base < nb; base += 1024u) {
-		const uint32_t i = base + threadIdx.x;
-		const uint32_t v = i < nb ? block_sums[i] : 0u;
-		uint32_t inc = v;
-		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
-		if (lane == 63u) s_wave[wave] = inc;
-		__syncthreads();
-		uint32_t off = s_carry;
-		for (uint32_t w = 0; w < wave; w++) off += s_wave[w];
-		if (i < nb) block_sums[i] = off + inc - v;
-		__syncthreads();
-		if (threadIdx.x == 1023u) s_carry = off + inc;
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
-		const uint32_t b = st->base[level & 1u];
-		st->count[(level + 1u) & 1u] = s_carry;
-		st->base[(level + 1u) & 1u] = b + count;
-		if (count) { st->total_nodes = b + count; st->depth = level + 1u; }
-	}
+	uint32_t r = 0;
+	for (int w = 0; w < COLLAPSE_BLOCK / 64; w++) r += s_w[w];
+	return r;
 }
 
-__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_emit(const int *jobs, const LevelState *st, uint32_t level, const uint2 *range,
-	const BinNode *bin, const int4 *dec, const uint32_t *info, const uint32_t *block_offsets, DevTri *tris, DevNode *nodes, int *next_jobs)
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_emit(int *jobs_a, int *jobs_b, LevelState *ring, uint32_t step, const uint2 *range,
+	const BinNode *bin, const int4 *dec, const uint32_t *info, const uint32_t *block_sums, DevTri *tris, DevNode *nodes)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
-	const uint32_t count = st->count[level & 1u];
-	const uint32_t base = st->base[level & 1u];
-	const uint32_t next_base = base + count;
+	__shared__ uint32_t s_r[COLLAPSE_BLOCK / 64];
+	const LevelState L = ring[step % COLLAPSE_RING];
+	int *next_jobs = (L.level & 1u) ? jobs_a : jobs_b;
+	const uint32_t count = L.count, base = L.base, next_base = base + count;
+	const uint32_t nb = (count + COLLAPSE_BLOCK - 1u) / COLLAPSE_BLOCK;
+	// jobs before this workgroup's first block of 256
+	uint32_t before = block_range_sum(block_sums, 0u, blockIdx.x < nb ? blockIdx.x : nb, s_r);
 	for (uint32_t vb = blockIdx.x; vb * COLLAPSE_BLOCK < count; vb += gridDim.x) {
 		const uint32_t j = vb * COLLAPSE_BLOCK + threadIdx.x;
 		const uint32_t inf = j < count ? info[j] : 0u;
 		const uint32_t n_inner = inf >> 8;
-		// exclusive scan of n_inner over the 256 jobs of this virtual block
+		// exclusive scan of n_inner over the 256 jobs of this block
 		const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 		uint32_t inc = n_inner;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
 		if (lane == 63u) s_w[wave] = inc;
 		__syncthreads();
-		uint32_t off = block_offsets[vb];
+		uint32_t off = before;
 		for (uint32_t w = 0; w < wave; w++) off += s_w[w];
 		off += inc - n_inner;
 		__syncthreads();
-		if (j >= count) continue;
-		const int4 d = dec[j];
-		const int ref[4] = { d.x, d.y, d.z, d.w };
-		const uint32_t nc = inf & 15u, mask = (inf >> 4) & 15u;
-		DevNode out;
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			out.pad[k] = 0;
-			if ((uint32_t)k >= nc) {
-				out.bx[0][k] = out.by[0][k] = out.bz[0][k] = +1.0f;   // inverted = never hit (rtk.c:1612-1620)
-				out.bx[1][k] = out.by[1][k] = out.bz[1][k] = -1.0f;
-				out.child[k] = RTK_REF_NONE;
-				continue;
-			}
-			float mn[3], mx[3];
-			const int r = ref[k];
-			if (r < 0) {
-				const uint32_t s = (uint32_t)~r;
-				tri_box(tris, s, mn, mx);
-				tris[s].spare = 1u;
-				tris[s].flags |= RTK_TRI_LAST;
-				out.child[k] = RTK_REF_LEAF | s;
-			} else {
-				const BinNode b = bin[r];
-				mn[0] = b.mn[0]; mn[1] = b.mn[1]; mn[2] = b.mn[2];
-				mx[0] = b.mx[0]; mx[1] = b.mx[1]; mx[2] = b.mx[2];
-				if (mask & (1u << k)) {
-					next_jobs[off] = r;
-					out.child[k] = next_base + off;
-					off++;
-				} else {
-					const uint2 rg = range[r];
-					tris[rg.x].spare = rg.y - rg.x + 1u;
-					tris[rg.y].flags |= RTK_TRI_LAST;
-					out.child[k] = RTK_REF_LEAF | rg.x;
-				}
-			}
-			out.bx[0][k] = mn[0]; out.bx[1][k] = mx[0];
-			out.by[0][k] = mn[1]; out.by[1][k] = mx[1];
-			out.bz[0][k] = mn[2]; out.bz[1][k] = mx[2];
-		}
-		nodes[base + j] = out;
+		if (j < count) collapse_emit_one(base + j, next_base, off, dec[j], inf, range, bin, tris, nodes, next_jobs);
+		const uint32_t hi = vb + gridDim.x < nb ? vb + gridDim.x : nb;
+		before += block_range_sum(block_sums, vb, hi, s_r);
 	}
+	// workgroup 0 has walked over every block sum: `before` is the size of the next level
+	if (blockIdx.x == 0 && threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = next_level(L, before);
+}
+
+// Up to max_levels levels, as long as a level has at most COLLAPSE_SMALL jobs; one workgroup.
+__global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(int *jobs_a, int *jobs_b, LevelState *ring, uint32_t step, uint32_t max_levels,
+	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes)
+{
+	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
+	LevelState L = ring[step % COLLAPSE_RING];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (uint32_t it = 0; it < max_levels && L.count != 0u && L.count <= COLLAPSE_SMALL; it++) {
+		const int *jobs = (L.level & 1u) ? jobs_b : jobs_a;
+		int *next_jobs = (L.level & 1u) ? jobs_a : jobs_b;
+		const uint32_t j = threadIdx.x;
+		int4 d = make_int4(0, 0, 0, 0);
+		uint32_t inf = 0, n_inner = 0;
+		if (j < L.count) n_inner = collapse_decide_one(jobs[j], lr, bin, d, inf);
+		uint32_t inc = n_inner;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+		if (lane == 63u) s_w[wave] = inc;
+		__syncthreads();
+		uint32_t off = 0, total = 0;
+		for (uint32_t w = 0; w < COLLAPSE_SMALL / 64; w++) { if (w < wave) off += s_w[w]; total += s_w[w]; }
+		off += inc - n_inner;
+		if (j < L.count) collapse_emit_one(L.base + j, L.base + L.count, off, d, inf, range, bin, tris, nodes, next_jobs);
+		L = next_level(L, total);
+		__threadfence();            // next_jobs and the leaf marks in tris[] are read by other threads of this workgroup next
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = L;
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -1076,7 +1131,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	need += padded(sort_words * 4) + padded(64) + padded(mesh_base.size() * 8);     // sort scratch, bounds, mesh_base
 	need += 2 * padded((size_t)n * 8) + 4 * padded((size_t)n * 4);                  // lr, range, parent_inner, parent_leaf, cont, arrive
 	need += padded((size_t)n * sizeof(BinNode));                                    // bin
-	need += 2 * padded((size_t)n * 4) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState));
+	need += 2 * padded((size_t)n * 4) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);
 	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case)
 	Workspace &ws = g_workspace[device];
 	std::lock_guard<std::mutex> ws_lock(ws.mutex);
@@ -1212,36 +1267,42 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	if (hipGetLastError() != hipSuccess) return fail("karras/refit");
 	stage("refit");
 
-	// ---- 8 collapse, three launches per level of the 4-wide tree, sizes stay on the device ----------
+	// ---- 8 collapse: one launch for the small levels at the top, two per big level, one for the tail -----
 	int *jobs_a = ar.take<int>(n), *jobs_b = ar.take<int>(n);
 	int4 *d_dec = ar.take<int4>(n);
 	uint32_t *d_info = ar.take<uint32_t>(n);
 	uint32_t *d_block_sums = ar.take<uint32_t>(collapse_blocks);
-	LevelState *d_state = ar.take<LevelState>(1);
+	LevelState *d_ring = ar.take<LevelState>(COLLAPSE_RING);
 	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
 	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
 	LevelState h_state = {};
 	{
-		h_state.count[0] = 1;
+		h_state.count = 1;
 		const int root_job = 0;
-		if (hipMemcpy(d_state, &h_state, sizeof(h_state), hipMemcpyHostToDevice) != hipSuccess ||
+		if (hipMemcpy(d_ring, &h_state, sizeof(h_state), hipMemcpyHostToDevice) != hipSuccess ||
 			hipMemcpy(jobs_a, &root_job, sizeof(root_job), hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
 	}
-	uint32_t level = 0;
-	for (;;) {
-		for (int k = 0; k < 8; k++, level++) {
-			// a level of the 4-wide tree has at most 4^level nodes, and never more than there are binary nodes
-			const uint64_t bound = level >= 15 ? (uint64_t)n : std::min<uint64_t>((uint64_t)1 << (2 * level), n);
-			const unsigned blocks = (unsigned)std::min<uint64_t>((bound + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
-			int *jin = (level & 1u) ? jobs_b : jobs_a, *jout = (level & 1u) ? jobs_a : jobs_b;
-			hipLaunchKernelGGL(k_collapse_decide, dim3(blocks), dim3(COLLAPSE_BLOCK), 0, 0, jin, d_state, level, d_lr, d_bin, d_dec, d_info, d_block_sums);
-			hipLaunchKernelGGL(k_collapse_scan, dim3(1), dim3(1024), 0, 0, d_block_sums, d_state, level);
-			hipLaunchKernelGGL(k_collapse_emit, dim3(blocks), dim3(COLLAPSE_BLOCK), 0, 0, jin, d_state, level, d_range, d_bin, d_dec, d_info,
-				d_block_sums, d_tris, d_nodes_tmp, jout);
+	{
+		const unsigned big_blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
+		// levels with more than COLLAPSE_SMALL jobs in a balanced 4-wide tree over n triangles, plus slack; a tree that is
+		// deeper than that takes further rounds
+		unsigned big_levels = 2;
+		for (uint64_t c = COLLAPSE_SMALL; c < n; c *= 4) big_levels++;
+		uint32_t step = 0;
+		for (unsigned round = 0;; round++) {
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, jobs_a, jobs_b, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			for (unsigned k = 0; k < big_levels; k++, step++) {
+				hipLaunchKernelGGL(k_collapse_decide, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, jobs_a, jobs_b, d_ring, step, d_lr, d_bin, d_dec, d_info, d_block_sums);
+				hipLaunchKernelGGL(k_collapse_emit, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, jobs_a, jobs_b, d_ring, step, d_range, d_bin, d_dec, d_info,
+					d_block_sums, d_tris, d_nodes_tmp);
+			}
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, jobs_a, jobs_b, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			if (hipGetLastError() != hipSuccess ||
+				hipMemcpy(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse");
+			if (h_state.count == 0) break;
+			if (round > 4096) return fail("collapse did not terminate");
+			big_levels = 4;
 		}
-		if (hipGetLastError() != hipSuccess || hipMemcpy(&h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse");
-		if (h_state.count[level & 1u] == 0) break;
-		if (level > 8192) return fail("collapse did not terminate");
 	}
 	const uint32_t total_nodes = h_state.total_nodes, depth = h_state.depth;
 	stage("collapse");
