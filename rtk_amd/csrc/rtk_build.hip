@@ -113,10 +113,12 @@ __device__ __forceinline__ float ord2f(uint32_t u)
 	return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// bounds[0..2] = min of centroid*2 (ordered uint), bounds[3..5] = max
-__global__ void k_bounds(const float *in_pos, uint32_t n, uint32_t *bounds)
+// bounds[0..2] = min of centroid*2 (ordered uint), bounds[3..5] = max. One 1024-thread workgroup per CU: the six result
+// words take ~300 atomics/us between them, and 2048 workgroups x 6 atomics cost four times the data pass at 1M triangles.
+#define BOUNDS_BLOCK 1024
+__global__ void __launch_bounds__(BOUNDS_BLOCK) k_bounds(const float *in_pos, uint32_t n, uint32_t *bounds)
 {
-	__shared__ float s_mn[3][SORT_BLOCK / 64], s_mx[3][SORT_BLOCK / 64];
+	__shared__ float s_mn[3][BOUNDS_BLOCK / 64], s_mx[3][BOUNDS_BLOCK / 64];
 	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		const float *p = in_pos + 9 * i;
@@ -141,7 +143,7 @@ __global__ void k_bounds(const float *in_pos, uint32_t n, uint32_t *bounds)
 	if (threadIdx.x < 3) {
 		const int a = threadIdx.x;
 		float lo = s_mn[a][0], hi = s_mx[a][0];
-		for (int w = 1; w < SORT_BLOCK / 64; w++) { lo = fminf(lo, s_mn[a][w]); hi = fmaxf(hi, s_mx[a][w]); }
+		for (int w = 1; w < BOUNDS_BLOCK / 64; w++) { lo = fminf(lo, s_mn[a][w]); hi = fmaxf(hi, s_mx[a][w]); }
 		atomicMin(&bounds[a], f2ord(lo));
 		atomicMax(&bounds[3 + a], f2ord(hi));
 	}
@@ -477,16 +479,29 @@ __device__ __forceinline__ BinNode combine_records(const BinNode &a, const BinNo
 // Finished records are written out once, coalesced. A thread that reaches a node whose range leaves the
 // tile stops and notes that node in cont[] for pass 2.
 #define REFIT_TILE 1024
-#define REFIT_BLOCK 256
+#define REFIT_BLOCK 1024        // one thread per triangle: every global load of the tile is in flight at once
 
 __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const int2 *lr, const uint2 *range,
 	const int *parent_inner, const int *parent_leaf, BinNode *bin, int *cont, BuildParams bp)
 {
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
-	__shared__ uint32_t s_arrive[REFIT_TILE];  // 4 KB
+	__shared__ uint32_t s_arrive[REFIT_TILE];  // 4 KB; bit 31: the node's range leaves the tile
+	__shared__ int2 s_lr[REFIT_TILE];          // 8 KB  } the tile's part of the topology, loaded once and coalesced: the climb
+	__shared__ int s_parent[REFIT_TILE];       // 4 KB  } below then never waits for global memory (it did three dependent
+	                                           //         loads per level, ~75 us per workgroup)
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
-	for (int k = threadIdx.x; k < REFIT_TILE; k += REFIT_BLOCK) s_arrive[k] = 0u;
+	for (int k = threadIdx.x; k < REFIT_TILE; k += REFIT_BLOCK) {
+		const int node = lo + k;
+		uint32_t a = 0x80000000u;
+		if (node < n - 1) {
+			const uint2 r = range[node];
+			if ((int)r.x >= lo && (int)r.y <= hi) a = 0u;
+			s_lr[k] = lr[node];
+			s_parent[k] = parent_inner[node];
+		}
+		s_arrive[k] = a;
+	}
 	__syncthreads();
 	for (int k = 0; k < REFIT_TILE / REFIT_BLOCK; k++) {
 		const int i = lo + k * REFIT_BLOCK + (int)threadIdx.x;
@@ -496,17 +511,17 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 		int node = parent_leaf[i];
 		int resume = -1;                        // node at which pass 2 continues for this thread, -1: none
 		while (node >= 0) {
-			const uint2 r = range[node];
-			if ((int)r.x < lo || (int)r.y > hi) { resume = node; break; }
+			// a Karras node is an end point of its own range: a node outside the tile has a range that leaves it
+			if (node < lo || node > hi || (s_arrive[node - lo] & 0x80000000u)) { resume = node; break; }
 			if (cur_ref >= 0) s_bin[cur_ref - lo] = cur;          // published before the arrival below (LDS is in order)
 			const uint32_t old = __hip_atomic_fetch_add(&s_arrive[node - lo], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (old == 0u) { cur_ref = -1 - n; break; }            // first arriver: the sibling's thread carries on
-			const int2 c = lr[node];
+			const int2 c = s_lr[node - lo];
 			const int sib = c.x == cur_ref ? c.y : c.x;
 			const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : s_bin[sib - lo];
 			cur = combine_records(cur, other, bp);
 			cur_ref = node;
-			node = parent_inner[node];
+			node = s_parent[node - lo];
 		}
 		if (cur_ref >= 0) s_bin[cur_ref - lo] = cur;              // finished subtree whose parent is outside the tile (or the root)
 		cont[i] = resume;
@@ -783,7 +798,14 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(int *jobs_a, 
 	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
-	LevelState L = ring[step % COLLAPSE_RING];
+	LevelState L;
+	if (step == 0u) {
+		// the very first launch of a build: level 0 is the root job (binary node 0)
+		L.count = 1u; L.base = 0u; L.level = 0u; L.total_nodes = 0u; L.depth = 0u; L.pad[0] = L.pad[1] = L.pad[2] = 0u;
+		if (threadIdx.x == 0) jobs_a[0] = 0;
+		__threadfence();
+		__syncthreads();
+	} else L = ring[step % COLLAPSE_RING];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	for (uint32_t it = 0; it < max_levels && L.count != 0u && L.count <= COLLAPSE_SMALL; it++) {
 		const int *jobs = (L.level & 1u) ? jobs_b : jobs_a;
@@ -1200,10 +1222,11 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
 	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());
 	{
-		static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-		BUILD_CHECK(hipMemcpy(d_bounds, init, sizeof(init), hipMemcpyHostToDevice));
-		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + SORT_BLOCK - 1) / SORT_BLOCK, (size_t)num_cus * 8);
-		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(SORT_BLOCK), 0, 0, in_pos, n, d_bounds);
+		// min words start at all ones, max words at zero (ordered-uint encoding): two fills, nothing the host waits for
+		BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, 0));
+		BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, 0));
+		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
+		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, 0, in_pos, n, d_bounds);
 		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos, n, d_bounds, keys_a, vals_a, 63u - key_bits);
 		BUILD_CHECK(hipGetLastError());
 	}
@@ -1217,6 +1240,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	stage("sort");
 
 	// ---- 5 emit: final triangle records in Morton order ----------------------------------
+	const std::vector<unsigned long long> mb(mesh_base.begin(), mesh_base.end());   // source of an async copy: lives until the final sync
 	rtk_dev_scene *ds = new rtk_dev_scene();
 	ds->device = device;
 	ds->num_cus = num_cus;
@@ -1244,8 +1268,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_slot_mesh = (uint32_t *)(tri_mem + o_smesh);
 	uint32_t *d_slot_tri = (uint32_t *)(tri_mem + o_stri);
 	{
-		std::vector<unsigned long long> mb(mesh_base.begin(), mesh_base.end());
-		if (hipMemcpy(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
+		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, 0) != hipSuccess) return fail("copy");
 		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos, in_vidx, vals, n, d_mesh_base,
 			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
@@ -1276,12 +1299,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
 	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
 	LevelState h_state = {};
-	{
-		h_state.count = 1;
-		const int root_job = 0;
-		if (hipMemcpy(d_ring, &h_state, sizeof(h_state), hipMemcpyHostToDevice) != hipSuccess ||
-			hipMemcpy(jobs_a, &root_job, sizeof(root_job), hipMemcpyHostToDevice) != hipSuccess) return fail("copy");
-	}
+	void *node_mem = nullptr;        // [DevNode x node_cap | DevNodeQ x node_cap], allocated while the collapse runs
+	size_t node_cap = 0;
 	{
 		const unsigned big_blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
 		// levels with more than COLLAPSE_SMALL jobs in a balanced 4-wide tree over n triangles, plus slack; a tree that is
@@ -1297,6 +1316,14 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 					d_block_sums, d_tris, d_nodes_tmp);
 			}
 			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, jobs_a, jobs_b, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			if (round == 0 && !node_mem) {
+				// While the GPU works through the levels: room for the final node arrays at the size 4-wide trees over n
+				// triangles usually have (0.47 n on the benchmark scenes); an exact allocation replaces it below if that is
+				// not enough. hipMalloc of ~1 GB after the read-back cost more than a tenth of a 1M-triangle build.
+				node_cap = (size_t)n / 2 + 4096;
+				if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) { (void)hipGetLastError(); node_mem = nullptr; node_cap = 0; }
+				else ds->allocs.push_back(node_mem);      // owned by the scene from here on (error paths free it with the scene)
+			}
 			if (hipGetLastError() != hipSuccess ||
 				hipMemcpy(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse");
 			if (h_state.count == 0) break;
@@ -1307,13 +1334,19 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	const uint32_t total_nodes = h_state.total_nodes, depth = h_state.depth;
 	stage("collapse");
 
-	// the node array at its final size
-	DevNode *d_nodes = (DevNode *)dev_alloc((size_t)total_nodes * sizeof(DevNode));
-	if (!d_nodes) return fail("out of device memory");
-	if (hipMemcpyAsync(d_nodes, d_nodes_tmp, (size_t)total_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail("copy");
+	// the node arrays at their final place
+	if (node_mem && total_nodes > node_cap) { ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr; }   // it was the last one pushed
+	if (!node_mem) {
+		node_cap = total_nodes ? total_nodes : 1;
+		if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
+		ds->allocs.push_back(node_mem);
+	}
+	ds->total_bytes += node_cap * (sizeof(DevNode) + sizeof(DevNodeQ));
+	DevNode *d_nodes = (DevNode *)node_mem;
 	ds->view.nodes = d_nodes;
 	ds->view.num_nodes = total_nodes;
-	if (rtk_quantize_nodes(ds, 0) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+	// one pass: exact nodes out of the workspace, compressed nodes beside them
+	if (rtk_quantize_nodes(ds, 0, d_nodes_tmp, (DevNodeQ *)(d_nodes + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
 	if (hipStreamSynchronize(0) != hipSuccess) return fail("sync");   // the workspace is handed back below
 
 	ds->view.tris = d_tris;

@@ -136,7 +136,8 @@ int rtk_blob_to_host_bvh(const rtk_scene *scene, size_t avail, HostBvh *out);
 rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
 
 // -- compressed node array (rtk_quant.hip): fills ds->view.qnodes from ds->view.nodes on `stream` --
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream);
+// src: read the exact nodes from there and store them to ds->view.nodes as well; dst: compressed array the caller allocated
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr);
 
 // -- radix sort shared with the builder (rtk_build.hip) --
 size_t rtk_sort_scratch_words(uint32_t n);

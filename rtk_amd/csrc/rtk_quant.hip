@@ -18,11 +18,13 @@ __device__ __forceinline__ float grid_step(float extent)
 	return s;
 }
 
-__global__ void k_quantize(const DevNode *nodes, uint32_t n, DevNodeQ *out)
+// copy_to: also store the exact node there (the device build hands its workspace copy over in the same pass)
+__global__ void k_quantize(const DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *copy_to)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const DevNode nd = nodes[i];
+	if (copy_to) copy_to[i] = nd;
 	DevNodeQ q;
 	const float *lo[3] = { nd.bx[0], nd.by[0], nd.bz[0] }, *hi[3] = { nd.bx[1], nd.by[1], nd.bz[1] };
 #pragma unroll
@@ -64,14 +66,18 @@ __global__ void k_quantize(const DevNode *nodes, uint32_t n, DevNodeQ *out)
 
 } // namespace
 
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream)
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst)
 {
 	const uint32_t n = ds->view.num_nodes;
-	void *p = nullptr;
-	RTK_HIP_CHECK(hipMalloc(&p, (size_t)(n ? n : 1) * sizeof(DevNodeQ)), RTK_AMD_ERR_OOM);
-	ds->allocs.push_back(p);
-	ds->total_bytes += (size_t)n * sizeof(DevNodeQ);
-	if (n) hipLaunchKernelGGL(k_quantize, dim3((n + 255u) / 256u), dim3(256), 0, stream, ds->view.nodes, n, (DevNodeQ *)p);
+	void *p = dst;
+	if (!p) {
+		RTK_HIP_CHECK(hipMalloc(&p, (size_t)(n ? n : 1) * sizeof(DevNodeQ)), RTK_AMD_ERR_OOM);
+		ds->allocs.push_back(p);
+		ds->total_bytes += (size_t)n * sizeof(DevNodeQ);
+	}
+	// src: the nodes still sit in a workspace; ds->view.nodes (allocated, not yet filled) receives them in the same pass
+	if (n) hipLaunchKernelGGL(k_quantize, dim3((n + 255u) / 256u), dim3(256), 0, stream, src ? src : ds->view.nodes, n, (DevNodeQ *)p,
+		src ? const_cast<DevNode *>(ds->view.nodes) : (DevNode *)nullptr);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	ds->view.qnodes = (const DevNodeQ *)p;
 	return RTK_AMD_OK;
