@@ -53,13 +53,21 @@ struct BuildParams {
 
 // ---------------------------------------------------------------------------------- 1 ingest
 
+// One decoded triangle in input order: 48 B = three 16-B pieces, so that the gather by sorted order in k_emit_tris
+// is three loads from (on average) 1.4 lines instead of twelve from two arrays.
+struct InTri {
+	float p[9];          // v0.xyz, v1.xyz, v2.xyz
+	uint32_t vi[3];      // original vertex indices (rtk_vertex.index)
+};
+static_assert(sizeof(InTri) == 48, "InTri");
+
 // IDX: 0 implicit (3i,3i+1,3i+2), 1 u16, 2 u32 (rtk.c:1028-1070). F64: positions are doubles (rtk.c:1098, B20).
 // Compile-time variants: the index and position formats are per mesh, so each launch is one straight-line path
 // (a run-time if/else-if/else form of this kernel faulted in round 1; its cause was never reduced, so nothing
 // is claimed about it -- every arm, RTK_TYPE_DEFAULT indices included, is covered by tests/test_gpu_build.py).
 template <int IDX, bool F64>
 __global__ void k_ingest(const char *pos, unsigned long long pos_stride, const char *idx,
-	unsigned long long idx_stride, uint32_t ntris, uint32_t base, float *in_pos, uint32_t *in_vidx)
+	unsigned long long idx_stride, uint32_t ntris, uint32_t base, InTri *in_tris)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= ntris) return;
@@ -75,7 +83,7 @@ __global__ void k_ingest(const char *pos, unsigned long long pos_stride, const c
 	}
 	const uint32_t vi[3] = { v0, v1, v2 };
 	const size_t g = (size_t)base + (size_t)i;
-	float *out = in_pos + 9 * g;
+	InTri rec;
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
 		float x, y, z;
@@ -86,19 +94,22 @@ __global__ void k_ingest(const char *pos, unsigned long long pos_stride, const c
 			const float *p = reinterpret_cast<const float *>(pos + (size_t)vi[c] * pos_stride);
 			x = p[0]; y = p[1]; z = p[2];
 		}
-		out[3 * c + 0] = x;
-		out[3 * c + 1] = y;
-		out[3 * c + 2] = z;
-		in_vidx[3 * g + c] = vi[c];
+		rec.p[3 * c + 0] = x;
+		rec.p[3 * c + 1] = y;
+		rec.p[3 * c + 2] = z;
+		rec.vi[c] = vi[c];
 	}
+	float4 *out = reinterpret_cast<float4 *>(in_tris + g);
+	const float4 *src = reinterpret_cast<const float4 *>(&rec);
+	out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
 }
 
 template <int IDX>
 void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
-	unsigned long long istride, uint32_t nt, uint32_t base, float *in_pos, uint32_t *in_vidx)
+	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris)
 {
-	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_pos, in_vidx);
-	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_pos, in_vidx);
+	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_tris);
+	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_tris);
 }
 
 // ---------------------------------------------------------------------------------- 2 bounds
@@ -116,12 +127,12 @@ __device__ __forceinline__ float ord2f(uint32_t u)
 // bounds[0..2] = min of centroid*2 (ordered uint), bounds[3..5] = max. One 1024-thread workgroup per CU: the six result
 // words take ~300 atomics/us between them, and 2048 workgroups x 6 atomics cost four times the data pass at 1M triangles.
 #define BOUNDS_BLOCK 1024
-__global__ void __launch_bounds__(BOUNDS_BLOCK) k_bounds(const float *in_pos, uint32_t n, uint32_t *bounds)
+__global__ void __launch_bounds__(BOUNDS_BLOCK) k_bounds(const InTri *in_tris, uint32_t n, uint32_t *bounds)
 {
 	__shared__ float s_mn[3][BOUNDS_BLOCK / 64], s_mx[3][BOUNDS_BLOCK / 64];
 	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-		const float *p = in_pos + 9 * i;
+		const float *p = in_tris[i].p;
 #pragma unroll
 		for (int a = 0; a < 3; a++) {
 			const float lo = fminf(fminf(p[a], p[3 + a]), p[6 + a]);
@@ -162,11 +173,11 @@ __device__ __forceinline__ unsigned long long spread21(uint32_t v)
 	return x;
 }
 
-__global__ void k_morton(const float *in_pos, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals, uint32_t drop_bits)
+__global__ void k_morton(const InTri *in_tris, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals, uint32_t drop_bits)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const float *p = in_pos + 9 * (size_t)i;
+	const float *p = in_tris[i].p;
 	uint32_t q[3];
 #pragma unroll
 	for (int a = 0; a < 3; a++) {
@@ -269,8 +280,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t *data, size_t 
 // stores form contiguous runs (16 keys on average for random digits) instead of one store per key.
 // Stable: tile order = wave order = chunk order = lane order.
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long long *keys_in, const uint32_t *vals_in, uint32_t n,
-	uint32_t shift, uint32_t num_units, const uint32_t *hist, unsigned long long *keys_out, uint32_t *vals_out)
+	uint32_t shift, uint32_t num_units, const uint32_t *hist, unsigned long long *keys_out, uint32_t *vals_out,
+	const uint32_t *scan_sums, uint32_t scan_blocks)
 {
+	__shared__ uint32_t s_bp[SORT_BLOCK];                    // scan_sums != NULL: exclusive prefix of the scan blocks' totals
 	__shared__ unsigned long long s_key[SORT_TILE];          // 32 KB
 	__shared__ uint32_t s_val[SORT_TILE];                    // 16 KB
 	__shared__ uint32_t s_cnt[SORT_BLOCK / 64][256];         // per wave: running count, then prefix over earlier waves
@@ -283,7 +296,21 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 	const uint32_t tile_n = (uint32_t)((size_t)n - tile_base < SORT_TILE ? (size_t)n - tile_base : SORT_TILE);
 
 	for (int j = 0; j < 4; j++) s_cnt[wave][lane + 64 * j] = 0;
-	s_global[threadIdx.x] = hist[(size_t)threadIdx.x * num_units + unit];
+	if (scan_sums) {
+		// hist holds scans local to blocks of SCAN_BLOCK * SCAN_ITEMS entries (k_scan_block); the totals of the blocks
+		// before an entry's block are added here (at most SORT_BLOCK of them) instead of by two more launches per pass
+		const uint32_t v = threadIdx.x < scan_blocks ? scan_sums[threadIdx.x] : 0u;
+		uint32_t inc = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+		if (lane == 63u) s_wsum[wave] = inc;
+		__syncthreads();
+		uint32_t off = 0;
+		for (uint32_t w = 0; w < wave; w++) off += s_wsum[w];
+		s_bp[threadIdx.x] = off + inc - v;
+		__syncthreads();
+		const size_t idx = (size_t)threadIdx.x * num_units + unit;
+		s_global[threadIdx.x] = hist[idx] + s_bp[idx / ((size_t)SCAN_BLOCK * SCAN_ITEMS)];
+	} else s_global[threadIdx.x] = hist[(size_t)threadIdx.x * num_units + unit];
 	__syncthreads();
 
 	// ---- phase 1: rank every key among the keys of its digit inside its wave
@@ -357,28 +384,29 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 
 // ---------------------------------------------------------------------------------- 5 emit
 
-__global__ void k_emit_tris(const float *in_pos, const uint32_t *in_vidx, const uint32_t *vals, uint32_t n,
+__global__ void k_emit_tris(const InTri *in_tris, const uint32_t *vals, uint32_t n,
 	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris, uint32_t *vertex_index,
 	uint32_t *prim_slot, uint32_t *slot_mesh, uint32_t *slot_tri)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n) return;
 	const uint32_t g = vals[s];
-	const float *p = in_pos + 9 * (size_t)g;
+	const float4 *src = reinterpret_cast<const float4 *>(in_tris + g);
+	const float4 a = src[0], b = src[1], c = src[2];      // p0 p1 p2 p3 | p4 p5 p6 p7 | p8 vi0 vi1 vi2
 	// mesh of global primitive g: last m with mesh_base[m] <= g
 	uint32_t lo = 0, hi = num_meshes;
 	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
 	DevTri t;
-	t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2]; t.prim = g;
-	t.v1[0] = p[3]; t.v1[1] = p[4]; t.v1[2] = p[5]; t.flags = lo << 8;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
-	t.v2[0] = p[6]; t.v2[1] = p[7]; t.v2[2] = p[8]; t.spare = 0u;
+	t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.prim = g;
+	t.v1[0] = a.w; t.v1[1] = b.x; t.v1[2] = b.y; t.flags = lo << 8;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
+	t.v2[0] = b.z; t.v2[1] = b.w; t.v2[2] = c.x; t.spare = 0u;
 #if RTK_TRI_STRIDE == 64
 	t.pad[0] = t.pad[1] = t.pad[2] = t.pad[3] = 0u;
 #endif
 	tris[s] = t;
-	vertex_index[3 * (size_t)s + 0] = in_vidx[3 * (size_t)g + 0];
-	vertex_index[3 * (size_t)s + 1] = in_vidx[3 * (size_t)g + 1];
-	vertex_index[3 * (size_t)s + 2] = in_vidx[3 * (size_t)g + 2];
+	vertex_index[3 * (size_t)s + 0] = __float_as_uint(c.y);
+	vertex_index[3 * (size_t)s + 1] = __float_as_uint(c.z);
+	vertex_index[3 * (size_t)s + 2] = __float_as_uint(c.w);
 	prim_slot[g] = s;
 	slot_mesh[s] = lo;
 	slot_tri[s] = g - (uint32_t)mesh_base[lo];
@@ -975,9 +1003,16 @@ bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b
 	for (uint32_t shift = 0; shift < key_bits; shift += 8) {
 		hipLaunchKernelGGL(k_sort_hist, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, n, shift, num_units, hist);
 		hipLaunchKernelGGL(k_scan_block, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
-		hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)scan_blocks);
-		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
-		hipLaunchKernelGGL(k_sort_scatter, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout);
+		if (scan_blocks <= SORT_BLOCK) {
+			// up to 2^24 keys: the scatter pass finishes the scan itself (three launches per pass instead of five)
+			hipLaunchKernelGGL(k_sort_scatter, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout,
+				sums, (uint32_t)scan_blocks);
+		} else {
+			hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)scan_blocks);
+			hipLaunchKernelGGL(k_scan_add, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
+			hipLaunchKernelGGL(k_sort_scatter, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout,
+				(const uint32_t *)nullptr, 0u);
+		}
 		std::swap(kin, kout);
 		std::swap(vin, vout);
 		in_b = !in_b;
@@ -1148,7 +1183,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	const size_t sort_words = rtk_sort_scratch_words(n);
 	const size_t collapse_blocks = ((size_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK;
 	size_t need = upload_bytes + 64 * 256;
-	need += padded(9 * (size_t)n * 4) + padded(3 * (size_t)n * 4);                  // in_pos, in_vidx
+	need += padded((size_t)n * sizeof(InTri));                                       // decoded triangles in input order
 	need += 2 * padded((size_t)n * 8) + 2 * padded((size_t)n * 4);                  // keys a/b, vals a/b
 	need += padded(sort_words * 4) + padded(64) + padded(mesh_base.size() * 8);     // sort scratch, bounds, mesh_base
 	need += 2 * padded((size_t)n * 8) + 4 * padded((size_t)n * 4);                  // lr, range, parent_inner, parent_leaf, cont, arrive
@@ -1172,8 +1207,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	stage("workspace");
 
 	// ---- 1 ingest ------------------------------------------------------------------
-	float *in_pos = ar.take<float>(9 * (size_t)n);
-	uint32_t *in_vidx = ar.take<uint32_t>(3 * (size_t)n);
+	InTri *in_tris = ar.take<InTri>(n);
 	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
 		const rtk_mesh *m = &desc->meshes[mi];
 		const MeshPlan &pl = plans[mi];
@@ -1184,8 +1218,12 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 			std::vector<float> pos9(9 * nt);
 			std::vector<uint32_t> vidx3(3 * nt);
 			decode_mesh_on_host(m, pos9.data(), vidx3.data());
-			BUILD_CHECK(hipMemcpy(in_pos + 9 * (size_t)base, pos9.data(), pos9.size() * 4, hipMemcpyHostToDevice));
-			BUILD_CHECK(hipMemcpy(in_vidx + 3 * (size_t)base, vidx3.data(), vidx3.size() * 4, hipMemcpyHostToDevice));
+			std::vector<InTri> recs(nt);
+			for (size_t t = 0; t < nt; t++) {
+				for (int c = 0; c < 9; c++) recs[t].p[c] = pos9[9 * t + c];
+				for (int c = 0; c < 3; c++) recs[t].vi[c] = vidx3[3 * t + c];
+			}
+			BUILD_CHECK(hipMemcpy(in_tris + base, recs.data(), recs.size() * sizeof(InTri), hipMemcpyHostToDevice));
 			continue;
 		}
 		// raw buffers go to the device as they are; the decode runs there
@@ -1201,9 +1239,9 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 			pos_ptr = d;
 		}
 		const unsigned iblocks = (unsigned)((nt + 255) / 256);
-		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_pos, in_vidx);
-		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_pos, in_vidx);
-		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_pos, in_vidx);
+		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris);
+		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris);
+		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris);
 		BUILD_CHECK(hipGetLastError());
 	}
 	stage("ingest");
@@ -1226,8 +1264,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, 0));
 		BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, 0));
 		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
-		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, 0, in_pos, n, d_bounds);
-		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos, n, d_bounds, keys_a, vals_a, 63u - key_bits);
+		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, 0, in_tris, n, d_bounds);
+		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, n, d_bounds, keys_a, vals_a, 63u - key_bits);
 		BUILD_CHECK(hipGetLastError());
 	}
 	stage("morton");
@@ -1269,7 +1307,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_slot_tri = (uint32_t *)(tri_mem + o_stri);
 	{
 		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, 0) != hipSuccess) return fail("copy");
-		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_pos, in_vidx, vals, n, d_mesh_base,
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, vals, n, d_mesh_base,
 			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
 	}
