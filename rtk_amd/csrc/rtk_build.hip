@@ -608,20 +608,22 @@ __global__ void k_refit_top(const DevTri *tris, int n, const int2 *lr, const int
 }
 
 // ---------------------------------------------------------------------------------- 8 collapse
-// Binary tree -> 128 B 4-wide nodes, breadth first, one level at a time. A job is one wide node = one
-// binary node that gets opened: its two children, then twice more the largest-area child that is still
-// an inner node (the reference collapses exactly two binary levels, rtk.c:1572-1592; the greedy rule
-// costs 2 % fewer node visits on the benchmark scene). Wide-node numbers come from prefix sums, not from
-// an atomic counter, so the node array is the same for every build of the same input:
-//   k_collapse_decide  per job: the (up to four) children and how many of them are wide nodes themselves;
-//                      per 256 jobs their sum
-//   k_collapse_emit    per job: write the 128 B node; its inner children become the next level's jobs. The
-//                      offset of a block of 256 jobs is the sum of the block sums before it, which every
-//                      block adds up for itself (a separate scan launch per level cost more than the reads)
-//   k_collapse_small   levels of at most 1024 jobs -- the top six and the last few -- decide, scan and emit
-//                      in ONE workgroup, several levels per launch
-// The level bookkeeping lives in device memory: launch number `step` reads ring entry step and writes entry
-// step+1, so nothing a running kernel reads is written by it. The host reads it back once per round.
+// Binary tree -> 128 B 4-wide nodes, breadth first. A job is one wide node = one binary node that gets opened:
+// its two children, then twice more the largest-area child that is still an inner node (the reference collapses
+// exactly two binary levels, rtk.c:1572-1592; the greedy rule costs 2 % fewer node visits on the benchmark
+// scene). Wide-node numbers come from prefix sums, not from an atomic counter, so the node array is the same for
+// every build of the same input. A node is written in two steps, each in whole 32-B sectors:
+//   k_collapse_open    one thread per job of a level: reads the binary records (the dependent-load chain, so it gets
+//                      all the parallelism there is), writes the node's boxes (96 B), marks its leaves in the triangle
+//                      array, and leaves behind what depends on a prefix sum: the four child words with binary
+//                      references in the slots of inner children (dec), which slots those are (info), and per 256
+//                      jobs their number
+//   k_collapse_number  per job: prefix sum of the inner children -> their node numbers; writes the child words
+//                      (32 B) and the next level's job list. A block adds up the block sums before it by itself.
+//   k_collapse_small   levels of at most 1024 jobs -- the top six and the last few -- both steps in ONE workgroup,
+//                      several levels per launch (also opens the root)
+// Level bookkeeping lives in device memory: launch number `step` reads ring entry step and writes entry step+1,
+// so nothing a running kernel reads is written by it. The host reads the ring once per round.
 #define COLLAPSE_BLOCK 256
 #define COLLAPSE_SMALL 1024
 #define COLLAPSE_RING 64
@@ -635,103 +637,132 @@ struct LevelState {
 	uint32_t pad[3];
 };
 
+struct CollapseBufs {
+	int *jobs;                // [job] binary node of the job (current level; LDS inside k_collapse_small)
+	int4 *dec;                // [job] child words, binary references where info says so
+	uint32_t *info;           // [job] inner-children mask << 4 | their number << 8
+	uint32_t *sums;           // [job / 256] inner children of those 256 jobs
+};
+
 struct Cand {
 	int ref;          // binary child: >= 0 inner, < 0 leaf ~slot
 	float area;       // > 0 only if the child may still be opened
+	float mn[3], mx[3];
 };
 
-__device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin)
+__device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin, const DevTri *tris)
 {
 	Cand c;
 	c.ref = ref;
 	c.area = -1.0f;
 	if (ref >= 0) {
 		const BinNode b = bin[ref];
+		c.mn[0] = b.mn[0]; c.mn[1] = b.mn[1]; c.mn[2] = b.mn[2];
+		c.mx[0] = b.mx[0]; c.mx[1] = b.mx[1]; c.mx[2] = b.mx[2];
 		if (!(b.cnt_flag & 0x80000000u)) c.area = half_area(b.mn, b.mx);
-	}
+	} else tri_box(tris, (uint32_t)~ref, c.mn, c.mx);
 	return c;
 }
 
-// The children of the wide node made from binary node b; returns how many of them are wide nodes themselves.
-__device__ __forceinline__ uint32_t collapse_decide_one(int b, const int2 *lr, const BinNode *bin, int4 &dec, uint32_t &info)
+// Opens binary node b as wide node `node_index`: chooses its (up to four) children and writes the node except for the
+// numbers of the children that are wide nodes themselves. Returns how many those are.
+__device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, const int2 *lr, const uint2 *range, const BinNode *bin,
+	DevTri *tris, DevNode *nodes, int4 &dec, uint32_t &info)
 {
 	Cand c[4];
 	int nc;
-	if (bin[b].cnt_flag & 0x80000000u) {
+	const BinNode self = bin[b];
+	if (self.cnt_flag & 0x80000000u) {
 		// the whole (sub)tree is one leaf: only the root of a tiny scene
 		c[0].ref = b; c[0].area = -1.0f;
+		c[0].mn[0] = self.mn[0]; c[0].mn[1] = self.mn[1]; c[0].mn[2] = self.mn[2];
+		c[0].mx[0] = self.mx[0]; c[0].mx[1] = self.mx[1]; c[0].mx[2] = self.mx[2];
 		nc = 1;
 	} else {
 		const int2 ch = lr[b];
-		c[0] = make_cand(ch.x, bin);
-		c[1] = make_cand(ch.y, bin);
+		c[0] = make_cand(ch.x, bin, tris);
+		c[1] = make_cand(ch.y, bin, tris);
 		nc = 2;
+		// (every index into c[] below is a compile-time constant after unrolling: a run-time index would put the 32-dword
+		// array into scratch memory, which made this function several times slower)
+#pragma unroll
 		for (int round = 0; round < 2; round++) {
-			int best = -1;
+			int best = -1, best_ref = 0;
 			float best_area = 0.0f;
-			for (int k = 0; k < nc; k++) if (c[k].area > best_area) { best_area = c[k].area; best = k; }
-			if (best < 0) break;
-			const int2 o = lr[c[best].ref];
-			c[best] = make_cand(o.x, bin);
-			c[nc] = make_cand(o.y, bin);
-			nc++;
+#pragma unroll
+			for (int k = 0; k < 4; k++) if (k < nc && c[k].area > best_area) { best_area = c[k].area; best = k; best_ref = c[k].ref; }
+			if (best >= 0) {
+				const int2 o = lr[best_ref];
+				const Cand left = make_cand(o.x, bin, tris), right = make_cand(o.y, bin, tris);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					if (k == best) c[k] = left;
+					if (k == nc) c[k] = right;
+				}
+				nc++;
+			}
 		}
 	}
 	uint32_t mask = 0, n_inner = 0;
 	int r[4] = { 0, 0, 0, 0 };
-	for (int k = 0; k < nc; k++) {
-		r[k] = c[k].ref;
-		if (c[k].area > 0.0f) { mask |= 1u << k; n_inner++; }
+	float4 rows[6];      // bx[0], bx[1], by[0], by[1], bz[0], bz[1]: the first 96 bytes of the node
+	float *out = reinterpret_cast<float *>(rows);
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		if (k >= nc) {
+			out[0 + k] = out[8 + k] = out[16 + k] = +1.0f;        // inverted = never hit (rtk.c:1612-1620)
+			out[4 + k] = out[12 + k] = out[20 + k] = -1.0f;
+			continue;
+		}
+		const int ref = c[k].ref;
+		if (ref < 0) {
+			const uint32_t sl = (uint32_t)~ref;
+			tris[sl].spare = 1u;
+			tris[sl].flags |= RTK_TRI_LAST;
+			r[k] = (int)(RTK_REF_LEAF | sl);
+		} else if (c[k].area > 0.0f) {
+			mask |= 1u << k;
+			n_inner++;
+			r[k] = ref;                                           // binary reference; becomes a node number when this level is numbered
+		} else {
+			const uint2 rg = range[ref];
+			tris[rg.x].spare = rg.y - rg.x + 1u;
+			tris[rg.y].flags |= RTK_TRI_LAST;
+			r[k] = (int)(RTK_REF_LEAF | rg.x);
+		}
+		out[0 + k] = c[k].mn[0]; out[4 + k] = c[k].mx[0];
+		out[8 + k] = c[k].mn[1]; out[12 + k] = c[k].mx[1];
+		out[16 + k] = c[k].mn[2]; out[20 + k] = c[k].mx[2];
 	}
-	dec = make_int4(r[0], r[1], r[2], r[3]);
-	info = (uint32_t)nc | (mask << 4) | (n_inner << 8);
+	// the boxes now (96 B = three whole 32-B sectors); the child words follow in ONE 32-B store when this node's level
+	// is numbered -- patching single words of a node written earlier made every patch a read-modify-write in memory
+	float4 *dst = reinterpret_cast<float4 *>(nodes + node_index);
+#pragma unroll
+	for (int q = 0; q < 6; q++) dst[q] = rows[q];
+	for (int k = nc; k < 4; k++) r[k] = (int)RTK_REF_NONE;
+	dec = make_int4(r[0], r[1], r[2], r[3]);                      // final child words, except the slots in `mask`: binary references
+	info = (mask << 4) | (n_inner << 8);
 	return n_inner;
 }
 
-// Wide node `node_index` from its decision; its inner children get the numbers next_base + off, off + 1, ...
-__device__ __forceinline__ void collapse_emit_one(uint32_t node_index, uint32_t next_base, uint32_t off, const int4 d, uint32_t inf,
-	const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, int *next_jobs)
+// Job `node_index`: its inner children get the numbers next_base + off, ...; the child words go out as one sector and
+// the children's binary references to next_jobs[off ...].
+__device__ __forceinline__ void collapse_number_children(uint32_t node_index, uint32_t next_base, uint32_t off, const int4 d,
+	uint32_t inf, DevNode *nodes, int *next_jobs)
 {
-	const int ref[4] = { d.x, d.y, d.z, d.w };
-	const uint32_t nc = inf & 15u, mask = (inf >> 4) & 15u;
-	DevNode out;
+	uint32_t ref[4] = { (uint32_t)d.x, (uint32_t)d.y, (uint32_t)d.z, (uint32_t)d.w };
+	const uint32_t mask = (inf >> 4) & 15u;
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		out.pad[k] = 0;
-		if ((uint32_t)k >= nc) {
-			out.bx[0][k] = out.by[0][k] = out.bz[0][k] = +1.0f;   // inverted = never hit (rtk.c:1612-1620)
-			out.bx[1][k] = out.by[1][k] = out.bz[1][k] = -1.0f;
-			out.child[k] = RTK_REF_NONE;
-			continue;
-		}
-		float mn[3], mx[3];
-		const int r = ref[k];
-		if (r < 0) {
-			const uint32_t sl = (uint32_t)~r;
-			tri_box(tris, sl, mn, mx);
-			tris[sl].spare = 1u;
-			tris[sl].flags |= RTK_TRI_LAST;
-			out.child[k] = RTK_REF_LEAF | sl;
-		} else {
-			const BinNode b = bin[r];
-			mn[0] = b.mn[0]; mn[1] = b.mn[1]; mn[2] = b.mn[2];
-			mx[0] = b.mx[0]; mx[1] = b.mx[1]; mx[2] = b.mx[2];
-			if (mask & (1u << k)) {
-				next_jobs[off] = r;
-				out.child[k] = next_base + off;
-				off++;
-			} else {
-				const uint2 rg = range[r];
-				tris[rg.x].spare = rg.y - rg.x + 1u;
-				tris[rg.y].flags |= RTK_TRI_LAST;
-				out.child[k] = RTK_REF_LEAF | rg.x;
-			}
-		}
-		out.bx[0][k] = mn[0]; out.bx[1][k] = mx[0];
-		out.by[0][k] = mn[1]; out.by[1][k] = mx[1];
-		out.bz[0][k] = mn[2]; out.bz[1][k] = mx[2];
+		if (!(mask & (1u << k))) continue;
+		next_jobs[off] = (int)ref[k];
+		ref[k] = next_base + off;
+		off++;
 	}
-	nodes[node_index] = out;
+	// child[4] and pad[4]: the last 32 bytes of the node, one sector
+	uint4 *dst = reinterpret_cast<uint4 *>(&nodes[node_index].child[0]);
+	dst[0] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+	dst[1] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __device__ __forceinline__ LevelState next_level(const LevelState &L, uint32_t next_count)
@@ -744,12 +775,11 @@ __device__ __forceinline__ LevelState next_level(const LevelState &L, uint32_t n
 	return N;
 }
 
-__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *jobs_a, const int *jobs_b, const LevelState *ring, uint32_t step,
-	const int2 *lr, const BinNode *bin, int4 *dec, uint32_t *info, uint32_t *block_sums)
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B, const LevelState *ring, uint32_t step, const int2 *lr, const uint2 *range,
+	const BinNode *bin, DevTri *tris, DevNode *nodes)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
 	const LevelState L = ring[step % COLLAPSE_RING];
-	const int *jobs = (L.level & 1u) ? jobs_b : jobs_a;
 	const uint32_t count = L.count;
 	for (uint32_t vb = blockIdx.x; vb * COLLAPSE_BLOCK < count; vb += gridDim.x) {
 		const uint32_t j = vb * COLLAPSE_BLOCK + threadIdx.x;
@@ -757,9 +787,9 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *j
 		if (j < count) {
 			int4 d;
 			uint32_t inf;
-			n_inner = collapse_decide_one(jobs[j], lr, bin, d, inf);
-			dec[j] = d;
-			info[j] = inf;
+			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, d, inf);
+			B.dec[j] = d;
+			B.info[j] = inf;
 		}
 		uint32_t sum = n_inner;
 		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -768,7 +798,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_decide(const int *j
 		if (threadIdx.x == 0) {
 			uint32_t t = 0;
 			for (int w = 0; w < COLLAPSE_BLOCK / 64; w++) t += s_w[w];
-			block_sums[vb] = t;
+			B.sums[vb] = t;
 		}
 		__syncthreads();
 	}
@@ -788,22 +818,20 @@ __device__ __forceinline__ uint32_t block_range_sum(const uint32_t *a, uint32_t 
 	return r;
 }
 
-__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_emit(int *jobs_a, int *jobs_b, LevelState *ring, uint32_t step, const uint2 *range,
-	const BinNode *bin, const int4 *dec, const uint32_t *info, const uint32_t *block_sums, DevTri *tris, DevNode *nodes)
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs B, LevelState *ring, uint32_t step, DevNode *nodes)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
 	__shared__ uint32_t s_r[COLLAPSE_BLOCK / 64];
 	const LevelState L = ring[step % COLLAPSE_RING];
-	int *next_jobs = (L.level & 1u) ? jobs_a : jobs_b;
 	const uint32_t count = L.count, base = L.base, next_base = base + count;
 	const uint32_t nb = (count + COLLAPSE_BLOCK - 1u) / COLLAPSE_BLOCK;
-	// jobs before this workgroup's first block of 256
-	uint32_t before = block_range_sum(block_sums, 0u, blockIdx.x < nb ? blockIdx.x : nb, s_r);
+	// inner children of the jobs before this workgroup's first block of 256
+	uint32_t before = block_range_sum(B.sums, 0u, blockIdx.x < nb ? blockIdx.x : nb, s_r);
 	for (uint32_t vb = blockIdx.x; vb * COLLAPSE_BLOCK < count; vb += gridDim.x) {
 		const uint32_t j = vb * COLLAPSE_BLOCK + threadIdx.x;
-		const uint32_t inf = j < count ? info[j] : 0u;
+		const uint32_t inf = j < count ? B.info[j] : 0u;
+		const int4 d = j < count ? B.dec[j] : make_int4(0, 0, 0, 0);
 		const uint32_t n_inner = inf >> 8;
-		// exclusive scan of n_inner over the 256 jobs of this block
 		const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 		uint32_t inc = n_inner;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
@@ -813,45 +841,69 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_emit(int *jobs_a, i
 		for (uint32_t w = 0; w < wave; w++) off += s_w[w];
 		off += inc - n_inner;
 		__syncthreads();
-		if (j < count) collapse_emit_one(base + j, next_base, off, dec[j], inf, range, bin, tris, nodes, next_jobs);
+		// (the job list is written over the one this level was opened from: nothing reads that any more)
+		if (j < count) collapse_number_children(base + j, next_base, off, d, inf, nodes, B.jobs);
 		const uint32_t hi = vb + gridDim.x < nb ? vb + gridDim.x : nb;
-		before += block_range_sum(block_sums, vb, hi, s_r);
+		before += block_range_sum(B.sums, vb, hi, s_r);
 	}
 	// workgroup 0 has walked over every block sum: `before` is the size of the next level
 	if (blockIdx.x == 0 && threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = next_level(L, before);
 }
 
-// Up to max_levels levels, as long as a level has at most COLLAPSE_SMALL jobs; one workgroup.
-__global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(int *jobs_a, int *jobs_b, LevelState *ring, uint32_t step, uint32_t max_levels,
+// Up to max_levels levels, as long as a level has at most COLLAPSE_SMALL jobs; one workgroup. It takes over a level
+// that is already opened (dec/info valid) and hands over one that is opened too, block sums included. Launch 0 of a
+// build opens the root first.
+__global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs B, LevelState *ring, uint32_t step, uint32_t max_levels,
 	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
+	__shared__ int s_ref[COLLAPSE_SMALL * 4];
+	__shared__ uint32_t s_sums[COLLAPSE_SMALL * 4 / COLLAPSE_BLOCK];
 	LevelState L;
 	if (step == 0u) {
-		// the very first launch of a build: level 0 is the root job (binary node 0)
+		// level 0 is the root job (binary node 0), wide node 0
 		L.count = 1u; L.base = 0u; L.level = 0u; L.total_nodes = 0u; L.depth = 0u; L.pad[0] = L.pad[1] = L.pad[2] = 0u;
-		if (threadIdx.x == 0) jobs_a[0] = 0;
+		if (threadIdx.x == 0) {
+			int4 d;
+			uint32_t inf;
+			B.sums[0] = collapse_open(0, 0u, lr, range, bin, tris, nodes, d, inf);
+			B.dec[0] = d;
+			B.info[0] = inf;
+		}
 		__threadfence();
 		__syncthreads();
 	} else L = ring[step % COLLAPSE_RING];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	for (uint32_t it = 0; it < max_levels && L.count != 0u && L.count <= COLLAPSE_SMALL; it++) {
-		const int *jobs = (L.level & 1u) ? jobs_b : jobs_a;
-		int *next_jobs = (L.level & 1u) ? jobs_a : jobs_b;
+		// number this level's jobs ...
 		const uint32_t j = threadIdx.x;
-		int4 d = make_int4(0, 0, 0, 0);
-		uint32_t inf = 0, n_inner = 0;
-		if (j < L.count) n_inner = collapse_decide_one(jobs[j], lr, bin, d, inf);
+		const uint32_t inf = j < L.count ? B.info[j] : 0u;
+		const int4 d = j < L.count ? B.dec[j] : make_int4(0, 0, 0, 0);
+		const uint32_t n_inner = inf >> 8;
 		uint32_t inc = n_inner;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
 		if (lane == 63u) s_w[wave] = inc;
+		if (threadIdx.x < COLLAPSE_SMALL * 4 / COLLAPSE_BLOCK) s_sums[threadIdx.x] = 0u;
 		__syncthreads();
 		uint32_t off = 0, total = 0;
 		for (uint32_t w = 0; w < COLLAPSE_SMALL / 64; w++) { if (w < wave) off += s_w[w]; total += s_w[w]; }
 		off += inc - n_inner;
-		if (j < L.count) collapse_emit_one(L.base + j, L.base + L.count, off, d, inf, range, bin, tris, nodes, next_jobs);
-		L = next_level(L, total);
-		__threadfence();            // next_jobs and the leaf marks in tris[] are read by other threads of this workgroup next
+		if (j < L.count) collapse_number_children(L.base + j, L.base + L.count, off, d, inf, nodes, s_ref);
+		const LevelState N = next_level(L, total);
+		__syncthreads();
+		// ... and open the next level's (every dec/info of this level is in registers by now)
+		for (uint32_t i = threadIdx.x; i < total; i += COLLAPSE_SMALL) {
+			int4 d2;
+			uint32_t inf2;
+			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, d2, inf2);
+			B.dec[i] = d2;
+			B.info[i] = inf2;
+			if (n2) atomicAdd(&s_sums[i / COLLAPSE_BLOCK], n2);
+		}
+		__syncthreads();
+		if (threadIdx.x < (total + COLLAPSE_BLOCK - 1u) / COLLAPSE_BLOCK) B.sums[threadIdx.x] = s_sums[threadIdx.x];
+		L = N;
+		__threadfence();            // dec/info/sums of the next level are read by other threads of this workgroup, or by the next launch
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = L;
@@ -1188,7 +1240,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	need += padded(sort_words * 4) + padded(64) + padded(mesh_base.size() * 8);     // sort scratch, bounds, mesh_base
 	need += 2 * padded((size_t)n * 8) + 4 * padded((size_t)n * 4);                  // lr, range, parent_inner, parent_leaf, cont, arrive
 	need += padded((size_t)n * sizeof(BinNode));                                    // bin
-	need += 2 * padded((size_t)n * 4) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);
+	need += padded((size_t)n * 16) + 2 * padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);   // collapse: dec, info, jobs, block sums, ring
 	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case)
 	Workspace &ws = g_workspace[device];
 	std::lock_guard<std::mutex> ws_lock(ws.mutex);
@@ -1328,11 +1380,12 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	if (hipGetLastError() != hipSuccess) return fail("karras/refit");
 	stage("refit");
 
-	// ---- 8 collapse: one launch for the small levels at the top, two per big level, one for the tail -----
-	int *jobs_a = ar.take<int>(n), *jobs_b = ar.take<int>(n);
-	int4 *d_dec = ar.take<int4>(n);
-	uint32_t *d_info = ar.take<uint32_t>(n);
-	uint32_t *d_block_sums = ar.take<uint32_t>(collapse_blocks);
+	// ---- 8 collapse: one launch for the small levels at the top, two per big level, one for the tail ---------
+	CollapseBufs cb;
+	cb.jobs = ar.take<int>(n);
+	cb.dec = ar.take<int4>(n);
+	cb.info = ar.take<uint32_t>(n);
+	cb.sums = ar.take<uint32_t>(collapse_blocks);
 	LevelState *d_ring = ar.take<LevelState>(COLLAPSE_RING);
 	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
 	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
@@ -1347,13 +1400,14 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		for (uint64_t c = COLLAPSE_SMALL; c < n; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, jobs_a, jobs_b, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
-			for (unsigned k = 0; k < big_levels; k++, step++) {
-				hipLaunchKernelGGL(k_collapse_decide, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, jobs_a, jobs_b, d_ring, step, d_lr, d_bin, d_dec, d_info, d_block_sums);
-				hipLaunchKernelGGL(k_collapse_emit, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, jobs_a, jobs_b, d_ring, step, d_range, d_bin, d_dec, d_info,
-					d_block_sums, d_tris, d_nodes_tmp);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			for (unsigned k = 0; k < big_levels; k++) {
+				// number the level of ring entry `step` (-> entry step + 1: the next level, not opened yet), then open that
+				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_nodes_tmp);
+				step++;
+				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
 			}
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, jobs_a, jobs_b, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
 			if (round == 0 && !node_mem) {
 				// While the GPU works through the levels: room for the final node arrays at the size 4-wide trees over n
 				// triangles usually have (0.47 n on the benchmark scenes); an exact allocation replaces it below if that is
