@@ -398,8 +398,10 @@ __global__ void k_emit_tris(const InTri *in_tris, const uint32_t *vals, uint32_t
 	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
 	DevTri t;
 	t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.prim = g;
-	t.v1[0] = a.w; t.v1[1] = b.x; t.v1[2] = b.y; t.flags = lo << 8;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
-	t.v2[0] = b.z; t.v2[1] = b.w; t.v2[2] = c.x; t.spare = 0u;
+	// every record starts out as a leaf of its own (count 1, last of its leaf); the collapse rewrites only the
+	// members of multi-triangle leaves
+	t.v1[0] = a.w; t.v1[1] = b.x; t.v1[2] = b.y; t.flags = (lo << 8) | RTK_TRI_LAST;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
+	t.v2[0] = b.z; t.v2[1] = b.w; t.v2[2] = c.x; t.spare = 1u;
 #if RTK_TRI_STRIDE == 64
 	t.pad[0] = t.pad[1] = t.pad[2] = t.pad[3] = 0u;
 #endif
@@ -716,18 +718,19 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 		}
 		const int ref = c[k].ref;
 		if (ref < 0) {
-			const uint32_t sl = (uint32_t)~ref;
-			tris[sl].spare = 1u;
-			tris[sl].flags |= RTK_TRI_LAST;
-			r[k] = (int)(RTK_REF_LEAF | sl);
+			// a leaf of one triangle: k_emit_tris wrote every record as exactly that (count 1, last-of-leaf set), so
+			// there is nothing to mark -- two 4-byte read-modify-writes per leaf here were the bulk of this kernel's time
+			r[k] = (int)(RTK_REF_LEAF | (uint32_t)~ref);
 		} else if (c[k].area > 0.0f) {
 			mask |= 1u << k;
 			n_inner++;
 			r[k] = ref;                                           // binary reference; becomes a node number when this level is numbered
 		} else {
+			// a subtree the SAH rule turned into one leaf: the count goes into its first record, and only the last one
+			// keeps the end mark
 			const uint2 rg = range[ref];
 			tris[rg.x].spare = rg.y - rg.x + 1u;
-			tris[rg.y].flags |= RTK_TRI_LAST;
+			for (uint32_t t = rg.x; t < rg.y; t++) { tris[t].flags &= ~RTK_TRI_LAST; tris[t + 1u].spare = 0u; }
 			r[k] = (int)(RTK_REF_LEAF | rg.x);
 		}
 		out[0 + k] = c[k].mn[0]; out[4 + k] = c[k].mx[0];
