@@ -191,8 +191,14 @@ __device__ __forceinline__ void pk_slab2(const PkLane &L, const PkNode &n, bool 
 		tn1 = sse_max(sse_max(nx.y, ny.y), sse_max(nz.y, L.tmin)); tf1 = sse_min(sse_min(fx.y, fy.y), sse_min(fz.y, L.t));
 	}
 	const float miss = __builtin_nanf("");
-	pay0 = (live && tn0 <= tf0 && (uint32_t)n.ch[C0] != RTK_REF_NONE) ? tn0 : miss;
-	pay1 = (live && tn1 <= tf1 && (uint32_t)n.ch[C0 + 1] != RTK_REF_NONE) ? tn1 : miss;
+	if (FAST) {
+		// empty slots carry inverted boxes (every producer of DevNode writes +1 / -1 there) and FAST rays are tame: see `special`
+		pay0 = (live && tn0 <= tf0) ? tn0 : miss;
+		pay1 = (live && tn1 <= tf1) ? tn1 : miss;
+	} else {
+		pay0 = (live && tn0 <= tf0 && (uint32_t)n.ch[C0] != RTK_REF_NONE) ? tn0 : miss;
+		pay1 = (live && tn1 <= tf1 && (uint32_t)n.ch[C0 + 1] != RTK_REF_NONE) ? tn1 : miss;
+	}
 }
 
 // All triangles of one leaf for the packet, in the reference's groups of four (rtk.c:212, 302-336).
@@ -309,8 +315,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			L.sx = __float_as_uint(dx) >> 31; L.sy = __float_as_uint(dy) >> 31; L.sz = __float_as_uint(dz) >> 31;
 			L.t = L.tmax; L.u = 0.0f; L.v = 0.0f; L.prim = RTK_PRIM_NONE;
 		}
-		const bool special = !(isfinite(L.rdx) && isfinite(L.rdy) && isfinite(L.rdz) && L.rdx != 0.0f && L.rdy != 0.0f && L.rdz != 0.0f &&
-			isfinite(L.ox) && isfinite(L.oy) && isfinite(L.oz) && L.tmin == L.tmin && L.tmax == L.tmax);
+		// "special": the slab products can be NaN, or -- new -- the ray is so far out or so extreme in direction that the
+		// inverted box of an empty child slot (+1 / -1 on every axis) could round to a non-empty interval. Everybody else
+		// (|origin| < 2^23, 2^-100 < |1/d| < 2^100) misses an empty slot by arithmetic alone: (1-o)*rd and (-1-o)*rd
+		// differ by 2*rd >= 2^-22 of their size, so near > far on every axis, and the FAST slab test below does not look
+		// at the child word at all (three scalar instructions per child and node step on a scalar unit that is 75 % busy).
+		const bool tame = fabsf(L.ox) < 0x1p23f && fabsf(L.oy) < 0x1p23f && fabsf(L.oz) < 0x1p23f &&
+			fabsf(L.rdx) > 0x1p-100f && fabsf(L.rdx) < 0x1p100f && fabsf(L.rdy) > 0x1p-100f && fabsf(L.rdy) < 0x1p100f &&
+			fabsf(L.rdz) > 0x1p-100f && fabsf(L.rdz) < 0x1p100f;
+		const bool special = !(tame && L.tmin == L.tmin && L.tmax == L.tmax);
 		// wave-uniform facts about the packet
 		const unsigned long long m_alive = __ballot(alive);
 		const bool wave_fast = __ballot(alive && special) == 0ull;
