@@ -239,6 +239,14 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 // LDS (or the spill area). A push that does not fit (impossible for a tree: the launcher refuses scenes
 // needing more than PK_WAVE_STACK entries and sizes the spill area from the depth) is dropped without
 // advancing sp and remembered in a wave-uniform flag that is reported once per tile.
+// PK_PUSH_LDS: the caller has checked that three more entries fit the LDS part (one scalar compare per node step
+// instead of two compares and two branches per push).
+#define PK_PUSH_LDS(dist_, ref_)                                                                                  \
+	do {                                                                                                          \
+		lds_t[sp][lane] = (dist_);                                                                                \
+		stack = stack_write(stack, (ref_), sp, lane);                                                             \
+		sp++;                                                                                                     \
+	} while (0)
 #define PK_PUSH(dist_, ref_)                                                                                      \
 	do {                                                                                                          \
 		if (sp < PK_LDS_STACK + p.spill_cap) {                                                                    \
@@ -387,7 +395,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
 					const bool swap = k1 < k0;
 					const float pfar = swap ? p0 : p1, pnear = swap ? p1 : p0;
-					PK_PUSH(pfar, swap ? r0 : r1);
+					if (sp + 3u <= PK_LDS_STACK) PK_PUSH_LDS(pfar, swap ? r0 : r1);
+					else PK_PUSH(pfar, swap ? r0 : r1);
 					live = pnear == pnear;
 					top = swap ? r1 : r0;
 				} else {
@@ -407,11 +416,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					PK_CSWAP(0, 1) PK_CSWAP(2, 3) PK_CSWAP(0, 2) PK_CSWAP(1, 3) PK_CSWAP(1, 2)
 #undef PK_CSWAP
 					// far children first so that the nearest is popped first (rtk.c:520-535)
+					if (sp + 3u <= PK_LDS_STACK) {
 #pragma unroll
-					for (int i = 3; i >= 1; i--) {
-						if (n_any > (uint32_t)i) {
-							PK_PUSH(pay[i], ref[i]);
-						}
+						for (int i = 3; i >= 1; i--) if (n_any > (uint32_t)i) PK_PUSH_LDS(pay[i], ref[i]);
+					} else {
+#pragma unroll
+						for (int i = 3; i >= 1; i--) if (n_any > (uint32_t)i) PK_PUSH(pay[i], ref[i]);
 					}
 					live = pay[0] == pay[0];
 					top = ref[0];
