@@ -222,12 +222,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					const float dkz = kz0 ? dx : (kz1 ? dy : dz);
 					shx = -dkx / dkz;
 					shy = -dky / dkz;
-					shz = 1.0f / dkz;
 					sox = kz0 ? oy : (kz1 ? oz : ox);
 					soy = kz0 ? oz : (kz1 ? ox : oy);
 					soz = kz0 ? ox : (kz1 ? oy : oz);
 					// rtk.c:410: true divides
 					rdx = 1.0f / dx; rdy = 1.0f / dy; rdz = 1.0f / dz;
+					shz = kz0 ? rdx : (kz1 ? rdy : rdz);          // 1 / d[kz] is one of the three reciprocals above, bit for bit
 					// near/far plane offsets inside the node by direction sign BIT (rtk.c:152-154, 458-463)
 					const uint32_t sx = __float_as_uint(dx) >> 31, sy = __float_as_uint(dy) >> 31, sz = __float_as_uint(dz) >> 31;
 					onx = sx * 16u;
