@@ -411,11 +411,11 @@ def main():
                      "kernel_mrays_s": round(n / (k_ms * 1e-3) / 1e6, 1)},
     }
     if args.bvh == "device" and build_ms_device_mesh:
-        # SURVEY.md section 8d, build formula with this build's sizes: 36 B positions in, 12 B (key, index) out,
-        # P sort passes x 24 B (12-B pair read + written), 2 x 32 B binary node (refit write, collapse read),
-        # 128 B x wide nodes per triangle + 48 B triangle record out
-        passes = 6 if cfg["num_tris"] < (1 << 24) else 8
-        bpt = 36 + 12 + passes * 24 + 64 + 128.0 * info["num_nodes"] / cfg["num_tris"] + 48
+        # SURVEY.md section 8d, build formula with this build's sizes: 36 B positions in, the sort item out (< 2^24 triangles:
+        # one 8-B word = 40-bit code over the index, 5 passes; else a 12-B (key, index) pair, 8 passes), P passes x item read +
+        # written, 2 x 32 B binary node (refit write, collapse read), 128 B x wide nodes per triangle + 48 B triangle record out
+        passes, item = (5, 8) if cfg["num_tris"] < (1 << 24) else (8, 12)
+        bpt = 36 + item + passes * 2 * item + 64 + 128.0 * info["num_nodes"] / cfg["num_tris"] + 48
         gbs = cfg["num_tris"] * bpt / (build_ms_device_mesh * 1e-3) / 1e9
         out["build"] = {"triangles": cfg["num_tris"], "ms": round(build_ms_device_mesh, 3), "what": "rtk_dev_scene_build, mesh resident in HBM, "
                         "wall time inside the library (all kernels, no PCIe)", "sort_passes": passes,

@@ -189,8 +189,15 @@ __global__ void k_morton(const InTri *in_tris, uint32_t n, const uint32_t *bound
 		uint32_t v = (uint32_t)(t * 2097152.0f);
 		q[a] = v > 2097151u ? 2097151u : v;
 	}
-	keys[i] = ((spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2])) >> drop_bits;   // most significant bits only
-	vals[i] = i;
+	const unsigned long long code = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+	if (vals) {
+		keys[i] = code >> drop_bits;                               // most significant bits only
+		vals[i] = i;
+	} else {
+		// fewer than 2^24 triangles: the top 40 bits of the code above the triangle's own number. One 8-byte word per
+		// triangle goes through five sort passes instead of a 12-byte pair through six.
+		keys[i] = ((code >> 23) << 24) | (unsigned long long)i;
+	}
 }
 
 // ---------------------------------------------------------------------------------- 4 radix sort
@@ -279,6 +286,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t *data, size_t 
 // out in that order: neighbouring threads hold neighbouring keys of the same digit, so the global
 // stores form contiguous runs (16 keys on average for random digits) instead of one store per key.
 // Stable: tile order = wave order = chunk order = lane order.
+// VALS = false: the words carry their payload themselves (sorted field above, index below): no value arrays at all.
+template <bool VALS>
 __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long long *keys_in, const uint32_t *vals_in, uint32_t n,
 	uint32_t shift, uint32_t num_units, const uint32_t *hist, unsigned long long *keys_out, uint32_t *vals_out,
 	const uint32_t *scan_sums, uint32_t scan_blocks)
@@ -324,7 +333,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 		const size_t i = wave_base + (size_t)c * 64u + lane;
 		const bool valid = i < n;
 		key[c] = valid ? keys_in[i] : ~0ull;
-		val[c] = valid ? vals_in[i] : 0u;
+		val[c] = (VALS && valid) ? vals_in[i] : 0u;
 		const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
 		unsigned long long same = __ballot(valid);
 #pragma unroll
@@ -367,7 +376,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 			const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
 			const uint32_t pos = s_start[d] + s_cnt[wave][d] + rnk[c];
 			s_key[pos] = key[c];
-			s_val[pos] = val[c];
+			if (VALS) s_val[pos] = val[c];
 		}
 	}
 	__syncthreads();
@@ -378,19 +387,19 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 		const uint32_t d = (uint32_t)(k >> shift) & 255u;
 		const uint32_t dst = s_global[d] + (i - s_start[d]);
 		keys_out[dst] = k;
-		vals_out[dst] = s_val[i];
+		if (VALS) vals_out[dst] = s_val[i];
 	}
 }
 
 // ---------------------------------------------------------------------------------- 5 emit
 
-__global__ void k_emit_tris(const InTri *in_tris, const uint32_t *vals, uint32_t n,
+__global__ void k_emit_tris(const InTri *in_tris, const uint32_t *vals, const unsigned long long *words, uint32_t n,
 	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris, uint32_t *vertex_index,
 	uint32_t *prim_slot, uint32_t *slot_mesh, uint32_t *slot_tri)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n) return;
-	const uint32_t g = vals[s];
+	const uint32_t g = vals ? vals[s] : (uint32_t)(words[s] & 0xffffffull);     // packed sort words carry the index in their low 24 bits
 	const float4 *src = reinterpret_cast<const float4 *>(in_tris + g);
 	const float4 a = src[0], b = src[1], c = src[2];      // p0 p1 p2 p3 | p4 p5 p6 p7 | p8 vi0 vi1 vi2
 	// mesh of global primitive g: last m with mesh_base[m] <= g
@@ -1045,8 +1054,9 @@ size_t rtk_sort_scratch_words(uint32_t n)
 	return hist + sums + 16;
 }
 
-bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a, uint32_t *vals_b,
-	uint32_t n, uint32_t key_bits, uint32_t *scratch, hipStream_t stream)
+// Bits [first_bit, last_bit) of the keys, 8 at a time, least significant digit first. vals_a == NULL: keys only.
+static bool sort_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+	uint32_t n, uint32_t first_bit, uint32_t last_bit, uint32_t *scratch, hipStream_t stream)
 {
 	const uint32_t num_units = (n + SORT_TILE - 1u) / SORT_TILE;
 	const size_t hist_n = 256 * (size_t)num_units;
@@ -1055,24 +1065,38 @@ bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b
 	unsigned long long *kin = keys_a, *kout = keys_b;
 	uint32_t *vin = vals_a, *vout = vals_b;
 	bool in_b = false;
-	for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+	for (uint32_t shift = first_bit; shift < last_bit; shift += 8) {
 		hipLaunchKernelGGL(k_sort_hist, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, n, shift, num_units, hist);
 		hipLaunchKernelGGL(k_scan_block, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
-		if (scan_blocks <= SORT_BLOCK) {
-			// up to 2^24 keys: the scatter pass finishes the scan itself (three launches per pass instead of five)
-			hipLaunchKernelGGL(k_sort_scatter, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout,
-				sums, (uint32_t)scan_blocks);
-		} else {
+		// up to 2^24 keys the scatter pass finishes the scan itself (three launches per pass instead of five)
+		const uint32_t *fused_sums = scan_blocks <= SORT_BLOCK ? sums : nullptr;
+		if (!fused_sums) {
 			hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)scan_blocks);
 			hipLaunchKernelGGL(k_scan_add, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
-			hipLaunchKernelGGL(k_sort_scatter, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout,
-				(const uint32_t *)nullptr, 0u);
 		}
+		if (vals_a) hipLaunchKernelGGL((k_sort_scatter<true>), dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, vin, n, shift, num_units, hist, kout, vout,
+			fused_sums, (uint32_t)scan_blocks);
+		else hipLaunchKernelGGL((k_sort_scatter<false>), dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, (const uint32_t *)nullptr, n, shift, num_units, hist,
+			kout, (uint32_t *)nullptr, fused_sums, (uint32_t)scan_blocks);
 		std::swap(kin, kout);
 		std::swap(vin, vout);
 		in_b = !in_b;
 	}
 	return in_b;
+}
+
+bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+	uint32_t n, uint32_t key_bits, uint32_t *scratch, hipStream_t stream)
+{
+	return sort_async(keys_a, keys_b, vals_a, vals_b, n, 0u, key_bits, scratch, stream);
+}
+
+// 64-bit words sorted by their bits [first_bit, last_bit); the bits below first_bit ride along (an index, a payload).
+// Stable, so words that start out in index order stay in index order inside equal fields. True: the result is in keys_b.
+bool rtk_sort_words_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t n, uint32_t first_bit, uint32_t last_bit,
+	uint32_t *scratch, hipStream_t stream)
+{
+	return sort_async(keys_a, keys_b, nullptr, nullptr, n, first_bit, last_bit, scratch, stream);
 }
 
 // =====================================================================================
@@ -1231,10 +1255,11 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	}
 
 	// ---- workspace -----------------------------------------------------------------------
-	// 63-bit Morton keys resolve 2^-21 of the scene per axis; for < 2^24 triangles the low 15 bits never
-	// decide a split that matters (lab: identical visit counts down to 30 bits at 1M triangles), so only
-	// the top 48 bits are kept and sorted: 6 radix passes instead of 8.
-	const uint32_t key_bits = n < (1u << 24) ? 48u : 63u;
+	// 63-bit Morton keys resolve 2^-21 of the scene per axis; for < 2^24 triangles the low bits never decide a
+	// split that matters (lab: identical visit counts down to 30 bits at 1M triangles), so the top 40 bits are kept
+	// and share one 64-bit word with the triangle's number: 5 radix passes over 8-byte words (see k_morton) instead of
+	// 8 over 12-byte pairs.
+	const uint32_t key_bits = 63u;
 	const size_t sort_words = rtk_sort_scratch_words(n);
 	const size_t collapse_blocks = ((size_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK;
 	size_t need = upload_bytes + 64 * 256;
@@ -1311,7 +1336,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	// ---- 2 bounds, 3 morton -----------------------------------------------------------
 	uint32_t *d_bounds = ar.take<uint32_t>(16);
 	unsigned long long *keys_a = ar.take<unsigned long long>(n), *keys_b = ar.take<unsigned long long>(n);
-	uint32_t *vals_a = ar.take<uint32_t>(n), *vals_b = ar.take<uint32_t>(n);
+	const bool packed = n < (1u << 24);          // index fits under a 40-bit code in one word
+	uint32_t *vals_a = packed ? nullptr : ar.take<uint32_t>(n), *vals_b = packed ? nullptr : ar.take<uint32_t>(n);
 	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
 	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());
 	{
@@ -1326,9 +1352,10 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	stage("morton");
 
 	// ---- 4 sort: no allocation, no host synchronisation ------------------------------------
-	const bool in_b = rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, 0);
-	const unsigned long long *keys = in_b ? keys_b : keys_a;
-	const uint32_t *vals = in_b ? vals_b : vals_a;
+	const bool in_b = packed ? rtk_sort_words_async(keys_a, keys_b, n, 24u, 64u, sort_scratch, 0)
+	                         : rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, 0);
+	const unsigned long long *keys = in_b ? keys_b : keys_a;      // packed: all different (the index is part of the word), in ascending order
+	const uint32_t *vals = packed ? nullptr : (in_b ? vals_b : vals_a);
 	BUILD_CHECK(hipGetLastError());
 	stage("sort");
 
@@ -1362,7 +1389,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_slot_tri = (uint32_t *)(tri_mem + o_stri);
 	{
 		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, 0) != hipSuccess) return fail("copy");
-		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, vals, n, d_mesh_base,
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, vals, keys, n, d_mesh_base,
 			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
 	}

@@ -143,6 +143,8 @@ int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src
 size_t rtk_sort_scratch_words(uint32_t n);
 bool rtk_sort_pairs_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t *vals_a, uint32_t *vals_b,
 	uint32_t n, uint32_t key_bits, uint32_t *scratch, hipStream_t stream);
+bool rtk_sort_words_async(unsigned long long *keys_a, unsigned long long *keys_b, uint32_t n, uint32_t first_bit, uint32_t last_bit,
+	uint32_t *scratch, hipStream_t stream);
 
 // -- trace launches (rtk_trace.hip) --
 int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
