@@ -277,11 +277,12 @@ def main():
         alg_bytes = per_ray_bytes
         unit = "ray: each lane fetches its own nodes (%d B) and triangles (48 B)" % lane_node_bytes
         if args.sort_rays:
-            # the re-ordering pre-pass is inside the timed region: origin bounds (32 B read), keys (32 B read, 12 B written),
-            # two radix passes over (8 B key, 4 B index) pairs (8 B histogram read + 12 B read + 12 B written each)
-            alg_bytes += n * (32 + 44 + 2 * 32)
+            # the re-ordering pre-pass is inside the timed region: keys (32 B ray read, one 8-B word written: cell key over the
+            # ray's number), two radix passes over the words (8 B histogram read + 8 B read + 8 B written each), and the
+            # 8-B word the traversal reads per ray instead of counting
+            alg_bytes += n * (32 + 8 + 2 * 24 + 8)
             per_ray_bytes = alg_bytes
-            unit += "; plus the ray re-ordering pre-pass (140 B per ray), timed with the traversal"
+            unit += "; plus the ray re-ordering pre-pass (96 B per ray), timed with the traversal"
     sync()
 
     for k in range(args.warmup):

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					__builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 				const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
 				if (!active && rank < take) {
-					ray_index = p.perm ? p.perm[w_next + rank] : (uint32_t)map_index(w_next + rank, p.image_w, p.image_h, p.tile_blocks);
+					ray_index = p.perm ? (uint32_t)p.perm[w_next + rank] : (uint32_t)map_index(w_next + rank, p.image_w, p.image_h, p.tile_blocks);   // perm: sort words, ray number in the low half
 					const float4 r0 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index));
 					const float4 r1 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
 					ox = r0.x; oy = r0.y; oz = r0.z;
@@ -598,7 +598,7 @@ __device__ __forceinline__ uint32_t cell_of_(float x, float lo, float hi, uint32
 }
 
 // Key = cell of the ray's origin inside the batch's (sampled) origin bounds.
-__global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals,
+__global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint32_t *bounds, unsigned long long *keys,
 	uint32_t cell_bits, uint32_t with_octant)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,15 +612,14 @@ __global__ void rtk_ray_keys_kernel(const rtk_ray *rays, uint32_t n, const uint3
 		const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rays + i) + 16);
 		key = (key << 3) | ((__float_as_uint(r0.w) >> 31) | ((__float_as_uint(r1.x) >> 31) << 1) | ((__float_as_uint(r1.y) >> 31) << 2));
 	}
-	keys[i] = key;
-	vals[i] = i;
+	keys[i] = ((unsigned long long)key << 32) | i;      // sorted by the key, the ray's number rides below it
 }
 
 // Key = cell, inside the SCENE's bounds (union of the root's child boxes), of the point where the ray's [min_t, max_t]
 // interval enters those bounds: the origin itself for rays that start inside (shadow / bounce rays), the entry point for
 // rays that start outside (camera rays, config 3). That is where traversal starts doing work, so rays of one key share
 // the nodes and leaves they touch. Rays that miss the bounds get the largest key: they end at the root, together.
-__global__ void rtk_ray_entry_keys_kernel(const rtk_ray *rays, uint32_t n, const DevNode *root, unsigned long long *keys, uint32_t *vals,
+__global__ void rtk_ray_entry_keys_kernel(const rtk_ray *rays, uint32_t n, const DevNode *root, unsigned long long *keys,
 	uint32_t cell_bits, uint32_t with_octant)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,8 +652,7 @@ __global__ void rtk_ray_entry_keys_kernel(const rtk_ray *rays, uint32_t n, const
 		key = morton_cells_(q, cell_bits);
 		if (with_octant) key = (key << 3) | ((__float_as_uint(d[0]) >> 31) | ((__float_as_uint(d[1]) >> 31) << 1) | ((__float_as_uint(d[2]) >> 31) << 2));
 	}
-	keys[i] = key;
-	vals[i] = i;
+	keys[i] = ((unsigned long long)key << 32) | i;      // sorted by the key, the ray's number rides below it
 }
 
 // Full rtk_hit from a compact record (rtk.c:372-380 copy-out).
@@ -861,29 +859,29 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			if (sc->d_sort) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_sort); }
 			sc->d_sort = nullptr;
 			sc->sort_capacity = 0;
-			// [keys_a | keys_b] 8 B each, [vals_a | vals_b] 4 B each, bounds 6 words + sort scratch
-			RTK_HIP_CHECK(hipMalloc(&sc->d_sort, n * 24 + (words + 16) * 4), RTK_AMD_ERR_OOM);
+			// [words_a | words_b] 8 B each, bounds 6 words + sort scratch
+			RTK_HIP_CHECK(hipMalloc(&sc->d_sort, n * 16 + (words + 16) * 4), RTK_AMD_ERR_OOM);
 			sc->sort_capacity = n;
 		}
 		unsigned long long *keys_a = (unsigned long long *)sc->d_sort, *keys_b = keys_a + sc->sort_capacity;
-		uint32_t *vals_a = (uint32_t *)(keys_b + sc->sort_capacity), *vals_b = vals_a + sc->sort_capacity;
-		uint32_t *bounds = vals_b + sc->sort_capacity, *scratch = bounds + 16;
+		uint32_t *bounds = (uint32_t *)(keys_b + sc->sort_capacity), *scratch = bounds + 16;
 		static const uint32_t cell_bits = getenv("RTK_AMD_SORT_CELL_BITS") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_CELL_BITS")) : 5u;
 		static const uint32_t with_octant = getenv("RTK_AMD_SORT_OCTANT") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_OCTANT")) : 0u;
 		static const int entry_key = getenv("RTK_AMD_SORT_KEY") ? atoi(getenv("RTK_AMD_SORT_KEY")) : 1;   // 0: origin cell in the batch's origin bounds
 		if (entry_key && ds->view.num_nodes) {
-			hipLaunchKernelGGL(rtk_ray_entry_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, ds->view.nodes, keys_a, vals_a,
+			hipLaunchKernelGGL(rtk_ray_entry_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, ds->view.nodes, keys_a,
 				cell_bits, with_octant);
 		} else {
 			static const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
 			RTK_HIP_CHECK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, stream), RTK_AMD_ERR_HIP);
 			hipLaunchKernelGGL(rtk_ray_bounds_kernel, dim3((unsigned)(ds->num_cus * 2)), dim3(256), 0, stream, d_rays, (unsigned long long)n,
 				(unsigned long long)(n >= (1u << 16) ? 61 : 1), bounds);
-			hipLaunchKernelGGL(rtk_ray_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, bounds, keys_a, vals_a,
+			hipLaunchKernelGGL(rtk_ray_keys_kernel, dim3((n32 + 255u) / 256u), dim3(256), 0, stream, d_rays, n32, bounds, keys_a,
 				cell_bits, with_octant);
 		}
-		const bool in_b = rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n32, 3u * cell_bits + (with_octant ? 3u : 0u), scratch, stream);
-		p.perm = in_b ? vals_b : vals_a;
+		// one 8-byte word per ray (key over the ray's number), no value array: two passes of 16 B per ray
+		const bool in_b = rtk_sort_words_async(keys_a, keys_b, n32, 32u, 32u + 3u * cell_bits + (with_octant ? 3u : 0u), scratch, stream);
+		p.perm = in_b ? keys_b : keys_a;
 	}
 	p.spill = sc->d_spill;
 	p.spill_stride = (uint32_t)(spill_cap ? sc->spill_lanes : 0);

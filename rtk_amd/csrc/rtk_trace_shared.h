@@ -24,7 +24,7 @@ struct TraceParams {
 	uint32_t refill_min;
 	uint32_t dynamic;
 	uint32_t node_exit;            // leave the node loop when fewer lanes than this still need node steps and a leaf is waiting
-	const uint32_t *perm;          // optional: trace rays in this order (ray reordering), results go to the ray's own slot
+	const unsigned long long *perm; // optional: trace rays in this order (sorted words of the ray reordering, ray number in the low 32 bits); results go to the ray's own slot
 	// built-in candidate filters (rtk_dev_filter, FILT kernels only); all optional
 	const rtk_hit_record *after;   // per ray: only candidates that come after (t, prim) in (t, prim) order
 	const uint32_t *ignore_prim;   // per ray: global primitive id that is never a candidate
