@@ -61,59 +61,6 @@ struct InTri {
 };
 static_assert(sizeof(InTri) == 48, "InTri");
 
-// IDX: 0 implicit (3i,3i+1,3i+2), 1 u16, 2 u32 (rtk.c:1028-1070). F64: positions are doubles (rtk.c:1098, B20).
-// Compile-time variants: the index and position formats are per mesh, so each launch is one straight-line path
-// (a run-time if/else-if/else form of this kernel faulted in round 1; its cause was never reduced, so nothing
-// is claimed about it -- every arm, RTK_TYPE_DEFAULT indices included, is covered by tests/test_gpu_build.py).
-template <int IDX, bool F64>
-__global__ void k_ingest(const char *pos, unsigned long long pos_stride, const char *idx,
-	unsigned long long idx_stride, uint32_t ntris, uint32_t base, InTri *in_tris)
-{
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= ntris) return;
-	uint32_t v0, v1, v2;
-	if (IDX == 0) {
-		v0 = 3u * i; v1 = 3u * i + 1u; v2 = 3u * i + 2u;
-	} else if (IDX == 1) {
-		const uint16_t *p = reinterpret_cast<const uint16_t *>(idx + (size_t)i * idx_stride);
-		v0 = p[0]; v1 = p[1]; v2 = p[2];
-	} else {
-		const uint32_t *p = reinterpret_cast<const uint32_t *>(idx + (size_t)i * idx_stride);
-		v0 = p[0]; v1 = p[1]; v2 = p[2];
-	}
-	const uint32_t vi[3] = { v0, v1, v2 };
-	const size_t g = (size_t)base + (size_t)i;
-	InTri rec;
-#pragma unroll
-	for (int c = 0; c < 3; c++) {
-		float x, y, z;
-		if (F64) {
-			const double *p = reinterpret_cast<const double *>(pos + (size_t)vi[c] * pos_stride);
-			x = (float)p[0]; y = (float)p[1]; z = (float)p[2];
-		} else {
-			const float *p = reinterpret_cast<const float *>(pos + (size_t)vi[c] * pos_stride);
-			x = p[0]; y = p[1]; z = p[2];
-		}
-		rec.p[3 * c + 0] = x;
-		rec.p[3 * c + 1] = y;
-		rec.p[3 * c + 2] = z;
-		rec.vi[c] = vi[c];
-	}
-	float4 *out = reinterpret_cast<float4 *>(in_tris + g);
-	const float4 *src = reinterpret_cast<const float4 *>(&rec);
-	out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
-}
-
-template <int IDX>
-void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
-	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris)
-{
-	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_tris);
-	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(256), 0, 0, pos, pstride, idx, istride, nt, base, in_tris);
-}
-
-// ---------------------------------------------------------------------------------- 2 bounds
-
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
 	const uint32_t b = __float_as_uint(f);
@@ -123,6 +70,88 @@ __device__ __forceinline__ float ord2f(uint32_t u)
 {
 	return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+
+// IDX: 0 implicit (3i,3i+1,3i+2), 1 u16, 2 u32 (rtk.c:1028-1070). F64: positions are doubles (rtk.c:1098, B20).
+// Compile-time variants: the index and position formats are per mesh, so each launch is one straight-line path
+// (a run-time if/else-if/else form of this kernel faulted in round 1; its cause was never reduced, so nothing
+// is claimed about it -- every arm, RTK_TYPE_DEFAULT indices included, is covered by tests/test_gpu_build.py).
+// The bounds of the triangle centroids (x2, see k_bounds) are taken in the same pass: one 1024-thread workgroup per CU at
+// most, so the six result words see a few hundred atomics, not tens of thousands.
+#define INGEST_BLOCK 1024
+template <int IDX, bool F64>
+__global__ void __launch_bounds__(INGEST_BLOCK) k_ingest(const char *pos, unsigned long long pos_stride, const char *idx,
+	unsigned long long idx_stride, uint32_t ntris, uint32_t base, InTri *in_tris, uint32_t *bounds)
+{
+	__shared__ float s_mn[3][INGEST_BLOCK / 64], s_mx[3][INGEST_BLOCK / 64];
+	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t i = blockIdx.x * INGEST_BLOCK + threadIdx.x; i < ntris; i += gridDim.x * INGEST_BLOCK) {
+		uint32_t v0, v1, v2;
+		if (IDX == 0) {
+			v0 = 3u * i; v1 = 3u * i + 1u; v2 = 3u * i + 2u;
+		} else if (IDX == 1) {
+			const uint16_t *p = reinterpret_cast<const uint16_t *>(idx + (size_t)i * idx_stride);
+			v0 = p[0]; v1 = p[1]; v2 = p[2];
+		} else {
+			const uint32_t *p = reinterpret_cast<const uint32_t *>(idx + (size_t)i * idx_stride);
+			v0 = p[0]; v1 = p[1]; v2 = p[2];
+		}
+		const uint32_t vi[3] = { v0, v1, v2 };
+		const size_t g = (size_t)base + (size_t)i;
+		InTri rec;
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			float x, y, z;
+			if (F64) {
+				const double *p = reinterpret_cast<const double *>(pos + (size_t)vi[c] * pos_stride);
+				x = (float)p[0]; y = (float)p[1]; z = (float)p[2];
+			} else {
+				const float *p = reinterpret_cast<const float *>(pos + (size_t)vi[c] * pos_stride);
+				x = p[0]; y = p[1]; z = p[2];
+			}
+			rec.p[3 * c + 0] = x;
+			rec.p[3 * c + 1] = y;
+			rec.p[3 * c + 2] = z;
+			rec.vi[c] = vi[c];
+		}
+		float4 *out = reinterpret_cast<float4 *>(in_tris + g);
+		const float4 *src = reinterpret_cast<const float4 *>(&rec);
+		out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
+#pragma unroll
+		for (int a = 0; a < 3; a++) {
+			const float lo = fminf(fminf(rec.p[a], rec.p[3 + a]), rec.p[6 + a]);
+			const float hi = fmaxf(fmaxf(rec.p[a], rec.p[3 + a]), rec.p[6 + a]);
+			const float c2 = lo + hi;
+			mn[a] = fminf(mn[a], c2);
+			mx[a] = fmaxf(mx[a], c2);
+		}
+	}
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		for (int o = 32; o > 0; o >>= 1) {
+			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+		}
+		if ((threadIdx.x & 63u) == 0) { s_mn[a][threadIdx.x >> 6] = mn[a]; s_mx[a][threadIdx.x >> 6] = mx[a]; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		const int a = threadIdx.x;
+		float lo = s_mn[a][0], hi = s_mx[a][0];
+		for (int w = 1; w < INGEST_BLOCK / 64; w++) { lo = fminf(lo, s_mn[a][w]); hi = fmaxf(hi, s_mx[a][w]); }
+		atomicMin(&bounds[a], f2ord(lo));
+		atomicMax(&bounds[3 + a], f2ord(hi));
+	}
+}
+
+template <int IDX>
+void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
+	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris, uint32_t *bounds)
+{
+	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(INGEST_BLOCK), 0, 0, pos, pstride, idx, istride, nt, base, in_tris, bounds);
+	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(INGEST_BLOCK), 0, 0, pos, pstride, idx, istride, nt, base, in_tris, bounds);
+}
+
+// ---------------------------------------------------------------------------------- 2 bounds
 
 // bounds[0..2] = min of centroid*2 (ordered uint), bounds[3..5] = max. One 1024-thread workgroup per CU: the six result
 // words take ~300 atomics/us between them, and 2048 workgroups x 6 atomics cost four times the data pass at 1M triangles.
@@ -1288,6 +1317,12 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 
 	// ---- 1 ingest ------------------------------------------------------------------
 	InTri *in_tris = ar.take<InTri>(n);
+	uint32_t *d_bounds = ar.take<uint32_t>(16);
+	// centroid bounds: min words start at all ones, max words at zero (ordered-uint encoding): two fills, nothing the host
+	// waits for. The decode kernels below take them in passing.
+	BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, 0));
+	BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, 0));
+	bool bounds_pass_needed = false;          // some mesh came in as host-decoded records
 	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
 		const rtk_mesh *m = &desc->meshes[mi];
 		const MeshPlan &pl = plans[mi];
@@ -1304,6 +1339,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 				for (int c = 0; c < 3; c++) recs[t].vi[c] = vidx3[3 * t + c];
 			}
 			BUILD_CHECK(hipMemcpy(in_tris + base, recs.data(), recs.size() * sizeof(InTri), hipMemcpyHostToDevice));
+			bounds_pass_needed = true;
 			continue;
 		}
 		// raw buffers go to the device as they are; the decode runs there
@@ -1318,10 +1354,10 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 			BUILD_CHECK(upload_staged(d, pl.pos_src, pl.pbytes));
 			pos_ptr = d;
 		}
-		const unsigned iblocks = (unsigned)((nt + 255) / 256);
-		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris);
-		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris);
-		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris);
+		const unsigned iblocks = (unsigned)std::min<size_t>((nt + INGEST_BLOCK - 1) / INGEST_BLOCK, (size_t)num_cus);
+		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds);
+		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds);
+		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds);
 		BUILD_CHECK(hipGetLastError());
 	}
 	stage("ingest");
@@ -1334,18 +1370,16 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	if (bp.max_leaf > 63) bp.max_leaf = 63;     // 6-bit count in the blob's leaf header (rtk.c:188)
 
 	// ---- 2 bounds, 3 morton -----------------------------------------------------------
-	uint32_t *d_bounds = ar.take<uint32_t>(16);
 	unsigned long long *keys_a = ar.take<unsigned long long>(n), *keys_b = ar.take<unsigned long long>(n);
 	const bool packed = n < (1u << 24);          // index fits under a 40-bit code in one word
 	uint32_t *vals_a = packed ? nullptr : ar.take<uint32_t>(n), *vals_b = packed ? nullptr : ar.take<uint32_t>(n);
 	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
 	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());
 	{
-		// min words start at all ones, max words at zero (ordered-uint encoding): two fills, nothing the host waits for
-		BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, 0));
-		BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, 0));
-		const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
-		hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, 0, in_tris, n, d_bounds);
+		if (bounds_pass_needed) {
+			const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
+			hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, 0, in_tris, n, d_bounds);
+		}
 		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, n, d_bounds, keys_a, vals_a, 63u - key_bits);
 		BUILD_CHECK(hipGetLastError());
 	}
