@@ -1098,7 +1098,8 @@ static bool sort_async(unsigned long long *keys_a, unsigned long long *keys_b, u
 		hipLaunchKernelGGL(k_sort_hist, dim3(num_units), dim3(SORT_BLOCK), 0, stream, kin, n, shift, num_units, hist);
 		hipLaunchKernelGGL(k_scan_block, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
 		// up to 2^24 keys the scatter pass finishes the scan itself (three launches per pass instead of five)
-		const uint32_t *fused_sums = scan_blocks <= SORT_BLOCK ? sums : nullptr;
+		static const bool allow_fused = !(getenv("RTK_AMD_SORT_FUSED_SCAN") && atoi(getenv("RTK_AMD_SORT_FUSED_SCAN")) == 0);   // 0: test the large-n path on small scenes
+		const uint32_t *fused_sums = (allow_fused && scan_blocks <= SORT_BLOCK) ? sums : nullptr;
 		if (!fused_sums) {
 			hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)scan_blocks);
 			hipLaunchKernelGGL(k_scan_add, dim3((unsigned)scan_blocks), dim3(SCAN_BLOCK), 0, stream, hist, hist_n, sums);
@@ -1371,7 +1372,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 
 	// ---- 2 bounds, 3 morton -----------------------------------------------------------
 	unsigned long long *keys_a = ar.take<unsigned long long>(n), *keys_b = ar.take<unsigned long long>(n);
-	const bool packed = n < (1u << 24);          // index fits under a 40-bit code in one word
+	// index fits under a 40-bit code in one word (RTK_AMD_SORT_PACKED=0: the >= 2^24-triangle path, for tests on small scenes)
+	const bool packed = n < (1u << 24) && !(getenv("RTK_AMD_SORT_PACKED") && atoi(getenv("RTK_AMD_SORT_PACKED")) == 0);
 	uint32_t *vals_a = packed ? nullptr : ar.take<uint32_t>(n), *vals_b = packed ? nullptr : ar.take<uint32_t>(n);
 	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
 	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());

@@ -457,3 +457,37 @@ def test_adversarial_distributions(api, oracle, name):
         assert np.allclose(rec["t"][qm], ohits["t"][omask], rtol=1e-5, atol=0)
     elif name == "all_identical":
         assert (rec["prim"][qm] == 0).all()                                        # 5000 copies: the lowest id wins every tie
+
+
+@pytest.mark.gpu
+def test_large_scene_sort_paths_on_a_small_scene():
+    """Scenes of 2^24 triangles and more sort (key, index) pairs in eight passes and scan the digit histogram with the
+    three-launch scan; smaller ones never take those paths. RTK_AMD_SORT_PACKED=0 / RTK_AMD_SORT_FUSED_SCAN=0 force them
+    (read once per process, hence the child process): the BVH must validate and trace like the oracle on its blob."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from rtk_amd import api, synth
+from oracle import pyoracle
+tris = synth.triangle_soup(50000, 0.05, seed=11)
+ds = api.DeviceScene.build([dict(positions=tris)])
+ok, c = ds.validate()
+assert ok and c["loose_boxes"] == 0, c
+rays = synth.rays_config1(4096)
+rec = ds.trace(rays, full=False)
+eh, em = pyoracle.trace(pyoracle.Blob(ds.export_blob()), rays)
+gm = rec["prim"] != 0xFFFFFFFF
+assert (gm == em).all() and (rec["prim"][gm] == eh["triangle_index"][em]).all() and (rec["t"][gm] == eh["t"][em]).all()
+print("OK", int(gm.sum()), c["content_hash"])
+''' % ROOT
+    outs = []
+    for env_extra in ({}, {"RTK_AMD_SORT_PACKED": "0", "RTK_AMD_SORT_FUSED_SCAN": "0"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+        outs.append(r.stdout.split())
+    assert int(outs[0][1]) > 500 and outs[0][1] == outs[1][1]        # same hits either way
