@@ -210,6 +210,14 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 	i32x4 tb;
 	s_load_tri(tris + (size_t)slot0 * RTK_TRI_STRIDE, ta, tb);
 	const uint32_t n = (uint32_t)tb[3];                                // leaf size rides in the first record
+	if (n == 1u) {
+		// the usual case (the device build's leaves hold 1.008 triangles on average): a lone triangle is a partial
+		// group, so it takes the double-precision edge functions, and there is nothing to snapshot or redo
+		if (COUNT && live) c_tris++;
+		if (COUNT && lane == 0) atomicAdd(counter + 8, 1ull);
+		pk_triangle<true, KZ>(L, live, ta, tb);
+		return;
+	}
 	for (uint32_t g = 0; g < n; g += 4u) {
 		const uint32_t m = n - g < 4u ? n - g : 4u;
 		const bool force = m < 4u;                                     // padding slots make the whole group double (rtk.c:306)
