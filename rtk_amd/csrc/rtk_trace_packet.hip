@@ -68,6 +68,14 @@ __device__ __forceinline__ void s_load_tri(const char *addr, i32x8 &a, i32x4 &b)
 		: "=&s"(a), "=&s"(b) : "s"(addr) : "memory");
 }
 
+// One float of this wave's LDS stack by its LDS byte address (the low half of its flat address): a real ds_read_b32.
+__device__ __forceinline__ float lds_read_f32(uint32_t addr)
+{
+	float v;
+	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+	return v;
+}
+
 __device__ __forceinline__ uint32_t stack_write(uint32_t stack, uint32_t value, uint32_t entry, uint32_t lane)
 {
 	// (v_writelane_b32 with an SGPR value AND an SGPR lane select breaks the one-SGPR constant-bus rule)
@@ -450,7 +458,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 				for (;;) {
 					if (sp == 0u) { done = true; break; }
 					sp--;
-					const float te = sp < PK_LDS_STACK ? lds_t[sp][lane] : spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane];
+					// (written any other way hipcc merges the LDS and the spill read into one flat_load on a selected pointer)
+					float te;
+					if (sp < PK_LDS_STACK) te = lds_read_f32((uint32_t)(size_t)&lds_t[sp][lane]);
+					else te = spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane];
 					live = alive && te <= L.t;
 					if (__ballot(live) != 0ull) {
 						top = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
