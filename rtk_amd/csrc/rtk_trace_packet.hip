@@ -401,12 +401,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					top = a0 ? ref[0] : (a1 ? ref[1] : (a2 ? ref[2] : ref[3]));
 				} else if (n_any == 2u) {
 					// two children: pick them out (wave-uniform slot numbers), one comparison, one push
-					const uint32_t m = any_mask;
-					const uint32_t i0 = (uint32_t)__builtin_ctz(m), i1 = (uint32_t)__builtin_ctz(m & (m - 1u));
-					const float p0 = i0 == 0u ? pay[0] : (i0 == 1u ? pay[1] : pay[2]);            // i0 is 0, 1 or 2
-					const float p1 = i1 == 1u ? pay[1] : (i1 == 2u ? pay[2] : pay[3]);            // i1 is 1, 2 or 3
-					const uint32_t r0 = i0 == 0u ? ref[0] : (i0 == 1u ? ref[1] : ref[2]);
-					const uint32_t r1 = i1 == 1u ? ref[1] : (i1 == 2u ? ref[2] : ref[3]);
+					// six possible pairs, one scalar branch each: plain register moves instead of selects of vector registers by
+					// scalar slot numbers (each such select is a compare, a 64-bit mask and a v_cndmask)
+					float p0, p1;
+					uint32_t r0, r1;
+					switch (any_mask) {
+					case 3u: p0 = pay[0]; p1 = pay[1]; r0 = ref[0]; r1 = ref[1]; break;
+					case 5u: p0 = pay[0]; p1 = pay[2]; r0 = ref[0]; r1 = ref[2]; break;
+					case 9u: p0 = pay[0]; p1 = pay[3]; r0 = ref[0]; r1 = ref[3]; break;
+					case 6u: p0 = pay[1]; p1 = pay[2]; r0 = ref[1]; r1 = ref[2]; break;
+					case 10u: p0 = pay[1]; p1 = pay[3]; r0 = ref[1]; r1 = ref[3]; break;
+					default: p0 = pay[2]; p1 = pay[3]; r0 = ref[2]; r1 = ref[3]; break;
+					}
 					const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
 					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
 					const bool swap = k1 < k0;
