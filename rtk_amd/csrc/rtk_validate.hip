@@ -65,7 +65,10 @@ __global__ void k_check_nodes(DevSceneView sc, uint32_t *slot_seen, uint32_t *no
 		const uint32_t ref = nd.child[k];
 		const float mn[3] = { nd.bx[0][k], nd.by[0][k], nd.bz[0][k] }, mx[3] = { nd.bx[1][k], nd.by[1][k], nd.bz[1][k] };
 		if (ref == RTK_REF_NONE) {
-			if (mn[0] <= mx[0] && mn[1] <= mx[1] && mn[2] <= mx[2]) report(c, C_BOX_VIOLATION, i);   // an empty slot must never be hit
+			// an empty slot must never be hit, and the packet kernel's fast slab test relies on the arithmetic alone for
+			// that (it does not read the child word): the inverted box every producer writes, +1 / -1 on every axis
+			// (rtk.c:1612-1620), nothing weaker
+			if (!(mn[0] == 1.0f && mn[1] == 1.0f && mn[2] == 1.0f && mx[0] == -1.0f && mx[1] == -1.0f && mx[2] == -1.0f)) report(c, C_BOX_VIOLATION, i);
 			continue;
 		}
 		float cmn[3] = { INFINITY, INFINITY, INFINITY }, cmx[3] = { -INFINITY, -INFINITY, -INFINITY };
