@@ -239,9 +239,12 @@ def test_special_rays_take_the_exact_min_max_path(api, oracle, scene1):
     d[k % 11 == 0, 1] = -0.0
     d[k % 13 == 0, 0] = 1e-42          # denormal: 1/d overflows to inf
     d[k % 17 == 0, 2] = 1e30
+    d[k % 37 == 0, 1] = 1e-33          # 1/d = 1e33: finite, but beyond what the packet kernel's fast slab test accepts (2^100)
+    d[k % 41 == 0, 0] = 3e31           # 1/d = 3e-32 < 2^-100: likewise
     d[k % 19 == 0] *= -1.0             # mixed signs in a wave
     d[k % 23 == 0] = d[k % 23 == 0][:, [2, 0, 1]]   # other dominant axes
     rays["origin"][k % 29 == 0, 0] = 0.5
+    rays["origin"][k % 43 == 0, 2] = -2.0e7   # |origin| >= 2^23: an empty child slot's +1/-1 box could round shut for such a ray
     # origins exactly on vertex coordinates of the scene: bound - origin == 0 happens for real
     tris = synth.scene_for_config(1)
     rays["origin"][k % 31 == 0, 0] = tris[(k[k % 31 == 0] * 3) % len(tris), 0]
