@@ -699,7 +699,10 @@ __device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin, const Dev
 		const BinNode b = bin[ref];
 		c.mn[0] = b.mn[0]; c.mn[1] = b.mn[1]; c.mn[2] = b.mn[2];
 		c.mx[0] = b.mx[0]; c.mx[1] = b.mx[1]; c.mx[2] = b.mx[2];
-		if (!(b.cnt_flag & 0x80000000u)) c.area = half_area(b.mn, b.mx);
+		// An inner node that is not one leaf can always be opened; the area only ranks the candidates. It can be ZERO
+		// (a box flat on two axes: triangles in a row, or extents that underflow) -- taking "area > 0" for "may be opened"
+		// turned such subtrees into single leaves of any size, which the 6-bit leaf count of the blob cannot even hold.
+		if (!(b.cnt_flag & 0x80000000u)) c.area = fmaxf(half_area(b.mn, b.mx), 1e-37f);
 	} else tri_box(tris, (uint32_t)~ref, c.mn, c.mx);
 	return c;
 }
