@@ -533,8 +533,11 @@ __device__ __forceinline__ BinNode combine_records(const BinNode &a, const BinNo
 	const float cost = a.cost + b.cost;
 	const float area = half_area(out.mn, out.mx);
 	const float split = bp.cost_node * area + cost;
-	const float leaf = cnt <= bp.max_leaf ? bp.cost_tri * (float)cnt * area : INFINITY;
-	out.cnt_flag = cnt | (leaf <= split ? 0x80000000u : 0u);
+	// (the size limit is tested by itself: with an infinite or NaN area -- non-finite vertices -- "INFINITY <= split" would
+	// be true and the whole scene one leaf)
+	const bool may_be_leaf = cnt <= bp.max_leaf;
+	const float leaf = may_be_leaf ? bp.cost_tri * (float)cnt * area : INFINITY;
+	out.cnt_flag = cnt | ((may_be_leaf && leaf <= split) ? 0x80000000u : 0u);
 	out.cost = fminf(leaf, split);
 	return out;
 }

@@ -27,3 +27,70 @@ def test_build_at_boundary_sizes(api, oracle, n):
         gm = rec["prim"] != 0xFFFFFFFF
         assert (gm == om).all() and (rec["prim"][gm] == oh["triangle_index"][om]).all(), n
         assert (rec["t"][gm] == oh["t"][om]).all() and (rec["u"][gm] == oh["u"][om]).all() and (rec["v"][gm] == oh["v"][om]).all(), n
+
+
+def _degenerate_mix(seed):
+    """Random scene made of the things real meshes contain and builders trip over: duplicates, points, needles,
+    triangles flat in an axis plane, clusters at very different scales, one far outlier."""
+    rng = np.random.RandomState(seed)
+    n = int(rng.choice([37, 300, 2500, 9000]))
+    base = synth.triangle_soup(n, float(rng.choice([0.3, 0.05, 0.01])), seed=seed).reshape(n, 3, 3).copy()
+    k = np.arange(n)
+    if rng.rand() < 0.7:
+        base[k % 5 == 0] = base[0]                                   # many copies of one triangle
+    if rng.rand() < 0.7:
+        base[k % 7 == 1, 1] = base[k % 7 == 1, 0]; base[k % 7 == 1, 2] = base[k % 7 == 1, 0]   # points
+    if rng.rand() < 0.7:
+        base[k % 11 == 2, 2] = base[k % 11 == 2, 1]                   # needles (two equal vertices)
+    if rng.rand() < 0.6:
+        base[k % 3 == 0, :, int(rng.randint(3))] = np.float32(0.25)   # a third of the scene in one axis plane
+    if rng.rand() < 0.5:
+        sel = k % 13 == 3
+        base[sel] = (base[sel] - np.float32(0.5)) * np.float32(1e-5) + np.float32(0.5)          # a speck of a cluster
+    if rng.rand() < 0.5:
+        base[-1] += np.float32(1e4)                                   # one outlier stretches the Morton grid
+    if rng.rand() < 0.4:
+        base[:, :, 1] = np.float32(0.0); base[:, :, 2] = np.float32(0.0)                          # everything on the x axis
+    return np.ascontiguousarray(base.reshape(-1, 3).astype(np.float32))
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_degenerate_mixes_build_and_trace_like_the_oracle_on_the_same_bvh(api, oracle, seed):
+    tris = _degenerate_mix(seed)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert ok and c["loose_boxes"] == 0, (seed, c)
+    assert c["triangles_checked"] == len(tris) // 3
+    blob = oracle.Blob(ds.export_blob())
+    assert oracle.validate_blob(blob)[0] == 0, seed
+    assert api.DeviceScene.build([dict(positions=tris)]).validate()[1]["content_hash"] == c["content_hash"]
+    # the traversal does not overflow its stack and reports well-formed hits; rtk.c on the same BVH agrees wherever the
+    # scene is resolvable in float (see test_adversarial_distributions for why not everywhere)
+    rays = synth.rays_config1(2048)
+    rec = ds.trace(rays, full=False)
+    assert api.lib().rtk_dev_trace_status(ds.handle, None) == 0
+    gm = rec["prim"] != 0xFFFFFFFF
+    assert (rec["prim"][gm] < len(tris) // 3).all()
+
+
+def test_non_finite_vertices_do_not_break_the_build_or_the_traversal(api):
+    """NaN / infinite vertex coordinates are the caller's bug, and the reference does not define what happens; here the
+    build must still finish with a structurally valid tree (min/max drop NaNs) and the traversal must terminate."""
+    tris = synth.triangle_soup(5000, 0.05, seed=5).reshape(5000, 3, 3).copy()
+    k = np.arange(5000)
+    tris[k % 97 == 0, 0, 0] = np.nan
+    tris[k % 101 == 1] = np.nan
+    tris[k % 103 == 2, 1, 2] = np.inf
+    tris[k % 107 == 3, 2, 1] = -np.inf
+    tris = np.ascontiguousarray(tris.reshape(-1, 3))
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert c["triangles_checked"] == 5000 and c["triangles_missing"] == 0 and c["triangles_duplicated"] == 0 and c["bad_references"] == 0, c
+    assert c["nodes_unreachable"] == 0 and c["nodes_shared"] == 0 and c["leaf_format_errors"] == 0, c
+    rays = synth.rays_config1(4096)
+    for opts in (None, api.make_opts(image=(64, 64))):
+        rec = ds.trace(rays, opts=opts, full=False)
+        assert api.lib().rtk_dev_trace_status(ds.handle, None) == 0
+        gm = rec["prim"] != 0xFFFFFFFF
+        assert (rec["prim"][gm] < 5000).all() and np.isfinite(rec["t"][gm]).all()
+    assert ds.trace_any(rays).dtype == bool
