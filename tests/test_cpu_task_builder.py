@@ -219,3 +219,37 @@ def test_random_mixed_meshes_through_the_task_graph(cpu_builder, oracle, seed):
         assert (hits[k][mask] == ohits[k][omask]).all()
     assert np.allclose(hits["t"][mask], ohits["t"][omask], rtol=1e-5, atol=0)
     assert (np.sort(hits["vertex"]["index"][mask], axis=1) == np.sort(ohits["vertex"]["index"][omask], axis=1)).all()
+
+
+def _adverse_scenes():
+    from tests.test_gpu_sizes import _degenerate_mix
+    scenes = {"mix%d" % s: _degenerate_mix(s) for s in (0, 3, 5, 8, 13)}
+    xs = np.arange(3000, dtype=np.float32) * np.float32(1e-3)
+    row = np.zeros((3000, 3, 3), np.float32)
+    row[:, 0, 0] = xs; row[:, 1, 0] = xs + np.float32(3e-4); row[:, 2, 0] = xs + np.float32(6e-4)
+    scenes["zero_area_row"] = np.ascontiguousarray(row.reshape(-1, 3))
+    nf = synth.triangle_soup(3000, 0.05, seed=5).reshape(3000, 3, 3).copy()
+    k = np.arange(3000)
+    nf[k % 97 == 0, 0, 0] = np.nan
+    nf[k % 101 == 1] = np.nan
+    nf[k % 103 == 2, 1, 2] = np.inf
+    nf[k % 107 == 3, 2, 1] = -np.inf
+    scenes["non_finite"] = np.ascontiguousarray(nf.reshape(-1, 3))
+    return scenes
+
+
+@pytest.mark.parametrize("name", ["mix0", "mix3", "mix5", "mix8", "mix13", "zero_area_row", "non_finite"])
+def test_task_graph_builder_survives_degenerate_input(cpu_builder, oracle, name):
+    """Duplicates, points, needles, axis-flat and collinear geometry, non-finite vertices: the task graph terminates and
+    the blob is structurally valid (every triangle in exactly one leaf, leaves of at most 63, offsets in range)."""
+    L = cpu_builder
+    tris = _adverse_scenes()[name]
+    ms = MeshSet([dict(positions=tris)])
+    first = Task()
+    b = L.rtk_start_build(C.byref(ms.desc), C.byref(first))
+    assert b
+    _run_serial(L, first)
+    blob = _finish(L, oracle, b)
+    assert oracle.validate_blob(blob)[0] == 0, name
+    rays = synth.rays_config1(512)
+    oracle.trace(blob, rays)          # terminates
