@@ -65,6 +65,15 @@ def gen_cfg1():
     save("cfg1_full.npz", scene_sha256=sha(tris), rays_sha256=sha(rays), **compact(hits, mask))
 
 
+def gen_exotic():
+    """2048 rays made of special values (synth.rays_exotic) through the REAL rtk_trace_ray over the config-1 leaf chain:
+    pins the oracle's ray set-up and leaf arithmetic where inputs are zero, denormal, huge, NaN or tied."""
+    tris = synth.scene_for_config(1)
+    rays = synth.rays_exotic(2048, tris=tris)
+    hits, mask = chain_reference(tris, rays)
+    save("exotic_rays.npz", scene_sha256=sha(tris), rays_sha256=sha(rays), **compact(hits, mask))
+
+
 def sample_indices(total, count, mult=4099):
     return ((np.arange(count, dtype=np.int64) * mult) % total).astype(np.int64)
 
@@ -298,6 +307,8 @@ def main():
         gen_edge()
     if "cfg1" in only:
         gen_cfg1()
+    if "exotic" in only:
+        gen_exotic()
     if only & {"cfg2", "cfg3", "near_ties"}:
         tris = synth.scene_for_config(2)
         if "near_ties" in only:

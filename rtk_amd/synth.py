@@ -119,3 +119,44 @@ CONFIGS = {
 def scene_for_config(cfg):
     c = CONFIGS[cfg]
     return triangle_soup(c["num_tris"], c["spread"], c["scene_seed"])
+
+
+def rays_exotic(n=2048, seed=9, tris=None):
+    """Rays full of the values that break sloppy implementations: zero, negative-zero, denormal, tiny and huge direction
+    components, equal-magnitude components (dominant-axis ties), origins far away, on vertex coordinates or in triangle
+    planes, empty / reversed / negative parameter intervals, NaN min_t (a NaN or infinite max_t makes the real
+    rtk.c run off its traversal stack -- rtk.c:477 asserts; its own "no limit" is FLT_MAX -- so those are not part of the
+    comparable domain). Deterministic; used against the real rtk.c
+    (oracle/gen_golden.py --only exotic) and against the GPU kernels."""
+    u = u01(seed, 0, n * 12).reshape(n, 12)
+    r = _rays(n)
+    o = u[:, 0:3] * np.float32(1.6) - np.float32(0.3)
+    d = u[:, 3:6] - np.float32(0.5)
+    k = np.arange(n)
+    specials = np.array([0.0, -0.0, 1e-42, -1e-42, 1e-30, 1e30, -1e30, 1.0, -1.0, 0.5], dtype=np.float32)
+    for axis in range(3):
+        sel = (u[:, 6 + axis] < np.float32(0.35))
+        pick = (u[:, 9 + axis] * np.float32(len(specials))).astype(np.int64) % len(specials)
+        d[sel, axis] = specials[pick[sel]]
+    d[k % 29 == 0] = np.float32([1.0, 1.0, 1.0]) * (u[k % 29 == 0, 3:4] - np.float32(0.5))      # |dx| = |dy| = |dz|
+    d[k % 31 == 0, 1] = d[k % 31 == 0, 0]                                                            # |dx| = |dy|
+    d[k % 211 == 0] = 0.0                                                                             # no direction at all
+    o[k % 37 == 0, 2] = np.float32(-2.5e7)
+    o[k % 41 == 0, 0] = np.float32(1e30)
+    if tris is not None:
+        t3 = np.asarray(tris, np.float32).reshape(-1, 3, 3)
+        sel = k % 17 == 0
+        o[sel] = t3[(k[sel] * 7) % len(t3), 0]                                                        # exactly on a vertex
+        sel = k % 19 == 0
+        o[sel, 0] = t3[(k[sel] * 11) % len(t3), 1, 0]                                                 # one coordinate of a vertex
+    r["origin"] = o
+    r["direction"] = d
+    r["min_t"] = 0.0
+    r["max_t"] = np.float32(3.402823e38)
+    r["min_t"][k % 13 == 0] = np.float32(-1.0)
+    r["min_t"][k % 23 == 0] = np.float32(0.75)
+    r["max_t"][k % 7 == 0] = np.float32(1.0)
+    r["max_t"][k % 43 == 0] = np.float32(0.0)             # empty interval
+    r["max_t"][k % 47 == 0] = np.float32(-1.0)            # reversed interval
+    r["min_t"][k % 53 == 0] = np.float32("nan")
+    return r

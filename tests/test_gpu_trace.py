@@ -256,3 +256,34 @@ def test_special_rays_take_the_exact_min_max_path(api, oracle, scene1):
         assert (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
         assert (hits["t"][mask] == oh["t"][om]).all() and (hits["u"][mask] == oh["u"][om]).all() and (hits["v"][mask] == oh["v"][om]).all()
     assert om.sum() > 500
+
+
+def test_exotic_rays_bit_exact_on_the_same_bvh(api, oracle, scene1):
+    """synth.rays_exotic (zeros, negative zeros, denormals, huge and tied direction components, far / on-vertex origins,
+    empty, reversed and NaN-min intervals; the oracle is pinned against the real rtk.c on exactly these rays in
+    tests/test_oracle_golden.py): every kernel returns what the oracle returns on the same BVH, bit for bit -- uploaded
+    SAH blob and device-built LBVH, per-lane and packet kernel, exact and compressed nodes, closest-hit and any-hit."""
+    blob, ds_up = scene1
+    tris = synth.scene_for_config(1)
+    rays = synth.rays_exotic(2048, tris=tris)
+    ds_dev = api.DeviceScene.build([dict(positions=tris)])
+    for ds, b in ((ds_up, blob), (ds_dev, oracle.Blob(ds_dev.export_blob()))):
+        oh, om = oracle.trace(b, rays)
+        assert om.sum() > 300
+        for opts in (None, api.make_opts(image=(32, 64)), api.make_opts(exact_nodes=True), api.make_opts(static=True)):
+            rec = ds.trace(rays, opts=opts, full=False)
+            gm = rec["prim"] != 0xFFFFFFFF
+            assert (gm == om).all()
+            hits, mask, _ = ds.trace(rays, opts=opts)
+            assert (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+            for f in ("t", "u", "v"):
+                assert (hits[f][mask].view(np.uint32) == oh[f][om].view(np.uint32)).all(), f
+        assert (ds.trace_any(rays) == om).all()
+    # outside the reference's domain (it runs off its stack, rtk.c:477): NaN and infinite max_t. Here: no hit, no hang
+    odd = rays[:256].copy()
+    odd["max_t"][0::2] = np.float32("nan")
+    odd["max_t"][1::2] = np.float32("inf")
+    for opts in (None, api.make_opts(image=(16, 16))):
+        rec = ds_dev.trace(odd, opts=opts, full=False)
+        assert api.lib().rtk_dev_trace_status(ds_dev.handle, None) == 0
+        assert (rec["prim"][0::2] == 0xFFFFFFFF).all()                 # NaN limit: nothing compares less than it

@@ -120,3 +120,20 @@ def test_ray_setup_vectors(oracle):
     assert list(k) == [2, 0, 1] and sm == 2
     k, sh, sm = oracle.ray_setup(ray((-0.0, 0.25, -2)))
     assert list(k) == [0, 1, 2] and sm == 5 and sh[2] == -0.5 and sh[1] == 0.125
+
+
+def test_exotic_rays_chain_bit_exact(oracle, golden_dir, scene1):
+    """2048 rays made of zeros, negative zeros, denormals, huge and tied direction components, far / on-vertex origins,
+    empty, reversed and NaN-min intervals (synth.rays_exotic): same leaf chain as the REAL rtk.c saw -> identical hit/miss,
+    ids and t/u/v bits. Pins the oracle's ray set-up (rtk.c:550-566) and leaf arithmetic where it is most fragile."""
+    g = load_golden(golden_dir, "exotic_rays.npz")
+    rays = synth.rays_exotic(2048, tris=scene1)
+    assert sha(scene1) == str(g["scene_sha256"]) and sha(rays) == str(g["rays_sha256"])
+    blobs = oracle.leaf_chain_blobs(scene1.reshape(-1, 3, 3))
+    hits, mask = oracle.trace_chain(blobs, rays)
+    gm = g["hit_mask"].astype(bool)
+    assert (mask == gm).all()
+    assert gm.sum() > 300
+    assert (hits["triangle_index"][mask] == g["hit_tri"][gm]).all()
+    for f, k in (("t", "hit_t"), ("u", "hit_u"), ("v", "hit_v")):
+        assert (hits[f][mask].view(np.uint32) == g[k][gm].view(np.uint32)).all(), f
