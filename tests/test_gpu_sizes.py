@@ -94,3 +94,34 @@ def test_non_finite_vertices_do_not_break_the_build_or_the_traversal(api):
         gm = rec["prim"] != 0xFFFFFFFF
         assert (rec["prim"][gm] < 5000).all() and np.isfinite(rec["t"][gm]).all()
     assert ds.trace_any(rays).dtype == bool
+
+
+@pytest.mark.parametrize("counts", [(0, 5, 0, 1), (0,), (0, 0), (1,), (0, 1, 0), (3000, 0, 2), (0, 0, 4097)])
+def test_scenes_with_empty_meshes(api, oracle, counts):
+    """Meshes without triangles between others, scenes of one triangle, scenes of none: the build goes through, mesh and
+    triangle indices keep their numbering (rtk.c:1168-1169), and an empty scene is traceable (everything misses)."""
+    meshes, total = [], 0
+    for mi, nt in enumerate(counts):
+        meshes.append(dict(positions=synth.triangle_soup(nt, 0.3, seed=40 + mi) if nt else np.zeros((0, 3), np.float32)))
+        total += nt
+    ds = api.DeviceScene.build(meshes)
+    info = ds.info()
+    assert info["num_triangles"] == total and info["num_meshes"] == len(counts)
+    rays = synth.rays_config1(1024)
+    hits, mask, rec = ds.trace(rays)
+    assert api.lib().rtk_dev_trace_status(ds.handle, None) == 0
+    if total == 0:
+        assert not mask.any()
+        return
+    ok, c = ds.validate()
+    assert ok, c
+    blob = oracle.Blob(ds.export_blob())
+    assert oracle.validate_blob(blob)[0] == 0
+    oh, om = oracle.trace(blob, rays)
+    assert (mask == om).all()
+    assert (hits["mesh_index"][mask] == oh["mesh_index"][om]).all() and (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+    nonempty = [mi for mi, nt in enumerate(counts) if nt]
+    assert set(np.unique(hits["mesh_index"][mask])) <= set(nonempty)
+    for opts in (api.make_opts(image=(32, 32)),):
+        rec2 = ds.trace(rays, opts=opts, full=False)
+        assert rec2.tobytes() == rec.tobytes()
