@@ -125,3 +125,34 @@ def test_scenes_with_empty_meshes(api, oracle, counts):
     for opts in (api.make_opts(image=(32, 32)),):
         rec2 = ds.trace(rays, opts=opts, full=False)
         assert rec2.tobytes() == rec.tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 257, 4097])
+def test_ray_batch_sizes_through_every_entry_point(api, oracle, n):
+    """Batches of 0, 1 and around every chunk size through closest-hit (per-lane, packet-shaped, static, sorted, exact
+    nodes), any-hit, filtered, counted and the host-pointer call: same answers as the oracle, no error left behind."""
+    tris = synth.scene_for_config(1)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    blob = oracle.Blob(ds.export_blob())
+    rays = synth.rays_config1(max(n, 1))[:n]
+    oh, om = oracle.trace(blob, rays) if n else (None, np.zeros(0, bool))
+    w = 1
+    while w * w < max(n, 1):
+        w += 1
+    shapes = [None, api.make_opts(static=True), api.make_opts(sort_rays=True), api.make_opts(exact_nodes=True)]
+    if n and n % w == 0:
+        shapes.append(api.make_opts(image=(w, n // w)))
+    for opts in shapes:
+        rec = ds.trace(rays, opts=opts, full=False)
+        assert len(rec) == n
+        gm = rec["prim"] != 0xFFFFFFFF
+        assert (gm == om).all()
+        if n:
+            assert (rec["prim"][gm] == oh["triangle_index"][om]).all() and (rec["t"][gm] == oh["t"][om]).all()
+    assert (ds.trace_any(rays) == om).all()
+    rec_f = ds.trace_filtered(rays, ignore_prim=np.full(n, 0xFFFFFFFF, np.uint32))
+    assert ((rec_f["prim"] != 0xFFFFFFFF) == om).all()
+    if n:
+        _, ctr = ds.trace_counted(rays)
+        assert ctr["rays"] == n
+    assert api.lib().rtk_dev_trace_status(ds.handle, None) == 0
