@@ -25,8 +25,10 @@
 // heads, each on its own 128-byte line (one word serves only ~88 atomics/us on MI355X).
 #define RTK_QUEUES 8
 #define RTK_QUEUE_WORD(q) (16 + 16 * (q))
-#define RTK_ERROR_WORD 10          // non-zero: a traversal stack overflowed (cannot happen for a validated tree)
 #define RTK_COUNTER_WORDS (16 + 16 * RTK_QUEUES)
+// non-zero: a traversal stack overflowed (cannot happen for a validated tree). One word past the ones a launch clears: it
+// stays set until rtk_trace_status has reported it.
+#define RTK_ERROR_WORD RTK_COUNTER_WORDS
 
 struct DevNode {
 	float bx[2][4];

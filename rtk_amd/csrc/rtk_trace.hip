@@ -737,7 +737,8 @@ LaunchScratch *scratch_for(rtk_dev_scene *ds, hipStream_t stream)
 	for (LaunchScratch *s : ds->scratch) if (s->stream == stream) return s;
 	LaunchScratch *s = new LaunchScratch();
 	s->stream = stream;
-	if (hipMalloc(&s->d_counter, RTK_COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+	if (hipMalloc(&s->d_counter, (RTK_COUNTER_WORDS + 1) * sizeof(unsigned long long)) != hipSuccess ||
+		hipMemset(s->d_counter, 0, (RTK_COUNTER_WORDS + 1) * sizeof(unsigned long long)) != hipSuccess) {
 		rtk_set_error("rtk_dev_trace: out of device memory (launch scratch)");
 		delete s;
 		return nullptr;
@@ -781,7 +782,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.cand_count = d_cand_count;
 	p.cand_k = cand_k;
 	p.n = n;
-	p.dynamic = 1;
+	p.dynamic = n > BLOCK_THREADS ? 1u : 0u;      // a batch that fits one workgroup needs no work queue (and no counter reset)
 	// Defaults from sweeps on MI355X (profiles/r01_sweep_opts*.log, r02_ab_r2o/p.log): leave the node
 	// loop once fewer than 32 lanes still descend (24 for image-shaped batches); image-shaped (tiled, coherent)
 	// batches refill a wave only when it is empty, everything else as soon as 8 lanes are idle.
@@ -888,18 +889,24 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.spill_cap = (uint32_t)spill_cap;
 	p.counter = sc->d_counter;
 
-	RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	// queue heads and visit counters start from zero; a one-block static launch uses neither
+	if (p.dynamic || packet || counted) RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
 	if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
 	else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	if (counted) {
-		unsigned long long c[16];
+		unsigned long long c[16], err = 0;
 		RTK_HIP_CHECK(hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+		RTK_HIP_CHECK(hipMemcpyAsync(&err, sc->d_counter + RTK_ERROR_WORD, sizeof(err), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
 		counted->rays = c[1]; counted->nodes = c[2]; counted->leaves = c[3];
 		counted->triangles = c[4]; counted->hits = c[5]; counted->stack_spills = c[6];
 		counted->wave_node_steps = c[7]; counted->wave_triangle_steps = c[8]; counted->wave_rays = c[9];
-		if (c[RTK_ERROR_WORD]) { rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)"); return RTK_AMD_ERR_BAD_SCENE; }
+		if (err) {
+			(void)hipMemsetAsync(sc->d_counter + RTK_ERROR_WORD, 0, sizeof(err), stream);
+			rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)");
+			return RTK_AMD_ERR_BAD_SCENE;
+		}
 	}
 	return RTK_AMD_OK;
 }
@@ -915,7 +922,11 @@ int rtk_trace_status(const rtk_dev_scene *ds_c, hipStream_t stream)
 		unsigned long long e = 0;
 		RTK_HIP_CHECK(hipMemcpyAsync(&e, s->d_counter + RTK_ERROR_WORD, sizeof(e), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
-		if (e) { rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)"); return RTK_AMD_ERR_BAD_SCENE; }
+		if (e) {
+			(void)hipMemsetAsync(s->d_counter + RTK_ERROR_WORD, 0, sizeof(e), stream);      // reported once
+			rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)");
+			return RTK_AMD_ERR_BAD_SCENE;
+		}
 		return RTK_AMD_OK;
 	}
 	RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
