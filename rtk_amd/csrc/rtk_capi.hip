@@ -229,7 +229,6 @@ extern "C" void rtk_amd_forget_scene(const rtk_scene *scene)
 
 namespace {
 
-const size_t HOST_CHUNK = (size_t)1 << 18;     // rays per piece: 8 MB of rays, 17 MB of full hits
 const size_t ZERO_COPY_RAYS = 2048;            // pieces up to this size are read and written in place by the kernels
 
 struct HostCtx {
@@ -332,14 +331,14 @@ bool HostCtx::ensure_candidates()
 
 thread_local HostCtx t_ctx;
 
-// One piece (n <= chunk capacity): rays up, trace (optionally restricted to candidates after h_after), expand,
-// hits and mask down. Returns false with the error set.
-bool trace_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n, bool want_hits, bool with_after)
+// One piece (n <= chunk capacity), first half: rays up, trace (optionally restricted to candidates after h_after),
+// expand, hits and mask on their way down -- everything enqueued on the context's stream, nothing waited for.
+bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n, bool want_hits, bool with_after)
 {
 	memcpy(c.h_rays, rays, n * sizeof(rtk_ray));
 	// Small pieces skip the copy engines altogether: the pinned staging memory is visible to the device, so the kernels
 	// read the rays from it and write hits and mask into it over PCIe themselves -- two launches and one synchronisation
-	// instead of those plus four copies (rtk_trace_ray: 74 us -> see profiles/r02_single_ray_latency.log).
+	// instead of those plus four copies (rtk_trace_ray: 74 us -> 50 us, profiles/r02_single_ray_latency.log).
 	const bool zero_copy = n <= ZERO_COPY_RAYS && !with_after;
 	const rtk_ray *d_rays = zero_copy ? c.h_rays : c.d_rays;
 	if (!zero_copy && hipMemcpyAsync(c.d_rays, c.h_rays, n * sizeof(rtk_ray), hipMemcpyHostToDevice, c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays: H2D copy failed"); return false; }
@@ -359,9 +358,23 @@ bool trace_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n, b
 		if (want_hits) ok = ok && hipMemcpyAsync(c.h_hits, c.d_hits, n * sizeof(rtk_hit), hipMemcpyDeviceToHost, c.stream) == hipSuccess;
 		if (!ok) { rtk_set_error("rtk_trace_rays: D2H copy failed: %s", hipGetErrorString(hipGetLastError())); return false; }
 	}
-	if (rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return false;      // synchronises the stream
 	return true;
 }
+
+// Second half: wait for the piece, then hand its results to the caller's arrays. Returns the hits, (size_t)-1 on error.
+size_t finish_piece(rtk_dev_scene *ds, HostCtx &c, size_t n, rtk_hit *hits, uint8_t *hit_mask)
+{
+	if (rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return (size_t)-1;      // synchronises the stream
+	size_t count = 0;
+	for (size_t i = 0; i < n; i++) {
+		if (c.h_mask[i]) { count++; if (hits) hits[i] = c.h_hits[i]; }           // misses stay untouched (rtk.c:571-576)
+		if (hit_mask) hit_mask[i] = c.h_mask[i];
+	}
+	return count;
+}
+
+thread_local HostCtx t_ctx2;                    // second staging set (own stream) for pipelined host-pointer batches
+const size_t PIPE_CHUNK = (size_t)1 << 15;      // rays per piece when a batch is pipelined
 
 } // namespace
 
@@ -371,18 +384,40 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 	if (n == 0) return 0;
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
-	HostCtx &c = t_ctx;
-	if (!c.ensure(n < HOST_CHUNK ? n : HOST_CHUNK)) return (size_t)-1;
-	size_t count = 0;
-	for (size_t at = 0; at < n; at += HOST_CHUNK) {
-		const size_t m = n - at < HOST_CHUNK ? n - at : HOST_CHUNK;
-		if (!trace_piece(ds, c, rays + at, m, hits != nullptr, false)) return (size_t)-1;
-		for (size_t i = 0; i < m; i++) {
-			if (c.h_mask[i]) { count++; if (hits) hits[at + i] = c.h_hits[i]; }   // misses stay untouched (rtk.c:571-576)
-			if (hit_mask) hit_mask[at + i] = c.h_mask[i];
-		}
+	if (n < 2 * PIPE_CHUNK) {
+		HostCtx &c = t_ctx;
+		if (!c.ensure(n)) return (size_t)-1;
+		if (!enqueue_piece(ds, c, rays, n, hits != nullptr, false)) return (size_t)-1;
+		return finish_piece(ds, c, n, hits, hit_mask);
 	}
-	return count;
+	// Two staging sets on two streams: while the GPU works on one piece the host copies the previous piece's results out
+	// and the next piece's rays in (both single-threaded memcpy-speed work that used to sit between the launches).
+	HostCtx *ctx[2] = { &t_ctx, &t_ctx2 };
+	if (!ctx[0]->ensure(PIPE_CHUNK) || !ctx[1]->ensure(PIPE_CHUNK)) return (size_t)-1;
+	size_t count = 0, piece = 0;
+	size_t at_of[2] = { 0, 0 }, n_of[2] = { 0, 0 };
+	bool busy[2] = { false, false }, failed = false;
+	for (size_t at = 0; at < n && !failed; at += PIPE_CHUNK, piece++) {
+		const int k = (int)(piece & 1u);
+		if (busy[k]) {
+			const size_t r = finish_piece(ds, *ctx[k], n_of[k], hits ? hits + at_of[k] : nullptr, hit_mask ? hit_mask + at_of[k] : nullptr);
+			busy[k] = false;
+			if (r == (size_t)-1) { failed = true; break; }
+			count += r;
+		}
+		const size_t m = n - at < PIPE_CHUNK ? n - at : PIPE_CHUNK;
+		if (!enqueue_piece(ds, *ctx[k], rays + at, m, hits != nullptr, false)) { failed = true; break; }
+		busy[k] = true; at_of[k] = at; n_of[k] = m;
+	}
+	// drain in submission order (the older piece first)
+	for (int j = 0; j < 2; j++) {
+		const int k = (int)((piece + (size_t)j) & 1u);
+		if (!busy[k]) continue;
+		const size_t r = finish_piece(ds, *ctx[k], n_of[k], hits ? hits + at_of[k] : nullptr, hit_mask ? hit_mask + at_of[k] : nullptr);
+		busy[k] = false;
+		if (r == (size_t)-1) failed = true; else count += r;
+	}
+	return failed ? (size_t)-1 : count;
 }
 
 // Batch form of rtk_trace_ray_filter (rtk.h:117, 130; a stub in the reference, rtk.c:579-582). Semantics:

@@ -14,7 +14,7 @@ from rtk_amd import api, synth  # noqa: E402
 
 tris = synth.scene_for_config(1)
 scene, keep = api.build_scene([dict(positions=tris)])
-rays = synth.rays_config1(65536)
+rays = synth.rays_config1(1048576)
 api.trace_ray(scene, rays[0])
 n = 3000
 t0 = time.perf_counter()
@@ -39,7 +39,7 @@ t0 = time.perf_counter()
 [t.join() for t in ts]
 dt = time.perf_counter() - t0
 print("rtk_trace_ray: 4 threads x 1000 calls in %.1f ms = %.1f us per call aggregate" % (dt * 1e3, dt / 4000 * 1e6), flush=True)
-for m in (64, 1024, 16384, 65536):
+for m in (64, 1024, 16384, 65536, 1048576):
     api.trace_rays(scene, rays[:m])
     t0 = time.perf_counter()
     for _ in range(20):
