@@ -71,6 +71,11 @@ def test_degenerate_mixes_build_and_trace_like_the_oracle_on_the_same_bvh(api, o
     assert api.lib().rtk_dev_trace_status(ds.handle, None) == 0
     gm = rec["prim"] != 0xFFFFFFFF
     assert (rec["prim"][gm] < len(tris) // 3).all()
+    # round trip: the exported blob loads again, validates, and gives the same answers ray for ray
+    ds2 = api.DeviceScene.upload(blob)
+    ok2, c2 = ds2.validate()
+    assert ok2, (seed, c2)
+    assert ds2.trace(rays, opts=api.make_opts(exact_nodes=True), full=False).tobytes() == ds.trace(rays, opts=api.make_opts(exact_nodes=True), full=False).tobytes()
 
 
 def test_non_finite_vertices_do_not_break_the_build_or_the_traversal(api):
