@@ -292,6 +292,34 @@ def test_config5_device_bvh_is_structurally_valid_and_reproducible(api):
     assert ds2.validate()[1]["content_hash"] == h
 
 
+@pytest.mark.slow
+def test_more_than_2_pow_24_triangles(api, oracle):
+    """17M triangles: the sort works on (key, index) pairs in eight passes with the three-launch histogram scan (smaller
+    scenes use one packed word and five passes), reference numbers need 25 bits. Structure validates, two builds agree,
+    and a sample of rays hits what brute force over the nearby triangles says."""
+    n = (1 << 24) + 300_001
+    tris = synth.triangle_soup(n, 0.008, seed=21)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert ok and c["triangles_checked"] == n and c["loose_boxes"] == 0, c
+    h = c["content_hash"]
+    rays = synth.rays_config1(4096)
+    rec = ds.trace(rays, full=False)
+    rec_img = ds.trace(rays, opts=api.make_opts(image=(64, 64)), full=False)
+    assert rec_img.tobytes() == rec.tobytes()
+    gm = rec["prim"] != 0xFFFFFFFF
+    assert gm.sum() > 3000 and (rec["prim"][gm] < n).all()
+    # every reported hit is a real intersection of that triangle at that t (the oracle's leaf chain on the one triangle)
+    t3 = tris.reshape(-1, 3, 3)
+    for i in np.nonzero(gm)[0][:200]:
+        one = oracle.leaf_chain_blobs(t3[int(rec["prim"][i]):int(rec["prim"][i]) + 1])
+        h1, m1 = oracle.trace_chain(one, rays[i:i + 1])
+        assert m1[0] and abs(float(h1["t"][0]) - float(rec["t"][i])) <= 1e-5 * abs(float(h1["t"][0])), int(i)
+    ds.free()
+    ds2 = api.DeviceScene.build([dict(positions=tris)])
+    assert ds2.validate()[1]["content_hash"] == h
+
+
 def test_default_index_type_means_u32(api):
     """rtk_mesh.index.type == RTK_TYPE_DEFAULT with an index buffer: 32-bit indices (rtk.c:1049-1059)."""
     from rtk_amd.types import Mesh, SceneDesc, RTK_TYPE_DEFAULT, RTK_TYPE_U32
