@@ -435,3 +435,44 @@ def test_filter_rejection_chains_longer_than_one_launch_collects(api, oracle):
         assert (oh["t"][om] == hits["t"][:512][om]).all()
     finally:
         api.free_scene(scene)
+
+
+def test_builds_and_traces_from_several_threads_at_once(api, oracle):
+    """Four host threads each build their own scenes (device builder, shared workspace behind a mutex), trace them through
+    the host-pointer and the device-pointer calls (pipelined pieces included) and free them, all at the same time: every
+    thread gets what a single-threaded run gets."""
+    import threading
+    sizes = [3000, 20000, 70000, 1500]
+    rays = synth.rays_config1(140000)
+    expect = {}
+    for k, n in enumerate(sizes):
+        tris = synth.triangle_soup(n, 0.05, seed=60 + k)
+        ds = api.DeviceScene.build([dict(positions=tris)])
+        expect[k] = (ds.validate()[1]["content_hash"], ds.trace(rays, full=False).tobytes())
+        ds.free()
+    errors = []
+
+    def worker(k):
+        try:
+            tris = synth.triangle_soup(sizes[k], 0.05, seed=60 + k)
+            for rep in range(3):
+                ds = api.DeviceScene.build([dict(positions=tris)])
+                ok, c = ds.validate()
+                if not ok or c["content_hash"] != expect[k][0]:
+                    errors.append(("hash", k, rep))
+                if ds.trace(rays, full=False).tobytes() != expect[k][1]:
+                    errors.append(("device trace", k, rep))
+                ds.free()
+                scene, keep = api.build_scene([dict(positions=tris)])
+                hits, mask = api.trace_rays(scene, rays)          # > 64k rays: two staging sets, two streams
+                rec = np.frombuffer(expect[k][1], dtype=[("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<u4")])
+                if not ((mask == (rec["prim"] != 0xFFFFFFFF)).all() and (hits["t"][mask] == rec["t"][mask]).all()
+                        and (hits["triangle_index"][mask] == rec["prim"][mask]).all()):
+                    errors.append(("host trace", k, rep))
+                api.free_scene(scene)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:6]
