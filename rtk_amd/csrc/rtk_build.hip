@@ -19,6 +19,7 @@
 //   8 collapse   breadth-first, level by level: binary tree -> 128 B 4-wide nodes
 #include "rtk_dev.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -452,45 +453,23 @@ __global__ void k_emit_tris(const InTri *in_tris, const uint32_t *vals, const un
 	slot_tri[s] = g - (uint32_t)mesh_base[lo];
 }
 
-// ---------------------------------------------------------------------------------- 6 karras
-
-__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j)
+// ---------------------------------------------------------------------------------- 6 tree topology
+// The binary radix tree over the sorted keys (Karras 2012 defines it) is not built by a pass of its own any more: the
+// refit pass below builds it bottom-up while it merges boxes (Apetrei 2014). A finished subtree over the sorted range
+// [L, R] looks at the two keys on either side of its borders: it is the LEFT child of node R if its right neighbour is
+// the more similar one (longer common prefix), else the RIGHT child of node L-1 -- an inner node is numbered by its split
+// position (node m separates sorted triangles m and m+1). Two subtrees meet at every node; the second to arrive merges
+// and climbs on. Same tree as the top-down search gives, without the search (0.33 ms at 10M triangles) and without the
+// parent arrays.
+//
+// similarity of sorted keys i and i+1: length of their common prefix; equal keys (only on the (key, index) pair path) are
+// told apart by their positions, as if the position were appended to the key. -1 outside the array.
+__device__ __forceinline__ int key_delta(const unsigned long long *keys, int n, int i)
 {
-	if (j < 0 || j >= n) return -1;
-	const unsigned long long a = keys[i], b = keys[j];
-	if (a == b) return 64 + __clz((unsigned)(i ^ j));
+	if (i < 0 || i >= n - 1) return -1;
+	const unsigned long long a = keys[i], b = keys[i + 1];
+	if (a == b) return 64 + __clz((unsigned)(i ^ (i + 1)));
 	return __clzll((long long)(a ^ b));
-}
-
-// children: >= 0 inner node index, < 0 leaf ~index. lr[i] = (left, right), range[i] = (first, last) sorted leaf covered.
-__global__ void k_karras(const unsigned long long *keys, int n, int2 *lr, uint2 *range, int *parent_inner, int *parent_leaf)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n - 1) return;
-	const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
-	const int dmin = delta(keys, n, i, i - d);
-	int lmax = 2;
-	while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
-	int l = 0;
-	for (int t = lmax >> 1; t >= 1; t >>= 1)
-		if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-	const int j = i + l * d;
-	const int dnode = delta(keys, n, i, j);
-	int s = 0;
-	int t = l;
-	do {
-		t = (t + 1) >> 1;
-		if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-	} while (t > 1);
-	const int gamma = i + s * d + (d < 0 ? -1 : 0);
-	const int lo = i < j ? i : j, hi = i < j ? j : i;
-	const int lc = lo == gamma ? ~gamma : gamma;
-	const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
-	lr[i] = make_int2(lc, rc);
-	range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);
-	if (lc >= 0) parent_inner[lc] = i; else parent_leaf[~lc] = i;
-	if (rc >= 0) parent_inner[rc] = i; else parent_leaf[~rc] = i;
-	if (i == 0) parent_inner[0] = -1;
 }
 
 // ---------------------------------------------------------------------------------- 7 refit + SAH
@@ -542,71 +521,84 @@ __device__ __forceinline__ BinNode combine_records(const BinNode &a, const BinNo
 	return out;
 }
 
-// Pass 1, tile-local. The sorted triangles are cut into tiles of REFIT_TILE; one workgroup owns a tile
-// and finishes every inner node whose whole range lies inside it. Such a node has its own index inside
-// the tile too (a Karras node is an end point of its range), so arrival counters and node records of the
-// tile live in LDS: the hand-off between the two threads that meet at a node never leaves the CU, which
-// is what made the all-global version cost ~14 memory-side atomics per node (3.8 ms at 10M triangles).
-// Finished records are written out once, coalesced. A thread that reaches a node whose range leaves the
-// tile stops and notes that node in cont[] for pass 2.
+// Pass 1, tile-local. The sorted triangles are cut into tiles of REFIT_TILE; one 1024-thread workgroup owns a tile and
+// builds every inner node whose two children lie inside it (split positions lo .. hi-1 with ranges inside [lo, hi]):
+// similarities, child links, range ends, arrival counters and the 32-B node records of the tile live in LDS, so a climb
+// waits for no global memory, and the hand-off between the two subtrees that meet at a node never leaves the CU (the
+// all-global version of round 1 cost ~14 memory-side atomics per node, 3.8 ms at 10M triangles). Finished nodes are
+// written out once, coalesced. A subtree whose parent lies across the tile border is left for pass 2 as a "climber":
+// (subtree, L, R), stored at the leaf that carried it.
 #define REFIT_TILE 1024
 #define REFIT_BLOCK 1024        // one thread per triangle: every global load of the tile is in flight at once
 
-__global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const int2 *lr, const uint2 *range,
-	const int *parent_inner, const int *parent_leaf, BinNode *bin, int *cont, BuildParams bp)
+struct Climb { int cur_ref; int l; int r; };      // cur_ref: >= 0 inner node, < 0 leaf ~slot; INT_MIN: none
+
+__global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
+	BinNode *bin, Climb *climbers, unsigned long long *half, uint32_t *arrive, int *root, BuildParams bp)
 {
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
-	__shared__ uint32_t s_arrive[REFIT_TILE];  // 4 KB; bit 31: the node's range leaves the tile
-	__shared__ int2 s_lr[REFIT_TILE];          // 8 KB  } the tile's part of the topology, loaded once and coalesced: the climb
-	__shared__ int s_parent[REFIT_TILE];       // 4 KB  } below then never waits for global memory (it did three dependent
-	                                           //         loads per level, ~75 us per workgroup)
+	__shared__ uint32_t s_arrive[REFIT_TILE];
+	__shared__ int s_left[REFIT_TILE], s_right[REFIT_TILE];     // children of node lo + k
+	__shared__ int s_rl[REFIT_TILE], s_rr[REFIT_TILE];          // its range
+	__shared__ int s_delta[REFIT_TILE + 1];                     // [k] = similarity across the border between lo+k-1 and lo+k
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
-	for (int k = threadIdx.x; k < REFIT_TILE; k += REFIT_BLOCK) {
-		const int node = lo + k;
-		uint32_t a = 0x80000000u;
-		if (node < n - 1) {
-			const uint2 r = range[node];
-			if ((int)r.x >= lo && (int)r.y <= hi) a = 0u;
-			s_lr[k] = lr[node];
-			s_parent[k] = parent_inner[node];
-		}
-		s_arrive[k] = a;
-	}
+	const int t = (int)threadIdx.x;
+	s_arrive[t] = 0u;
+	s_left[t] = INT_MIN;
+	s_right[t] = INT_MIN;
+	if (lo + t - 1 <= hi) s_delta[t] = key_delta(keys, n, lo + t - 1);
+	if (t == 0 && hi - lo + 1 == REFIT_TILE) s_delta[REFIT_TILE] = key_delta(keys, n, hi);
 	__syncthreads();
-	for (int k = 0; k < REFIT_TILE / REFIT_BLOCK; k++) {
-		const int i = lo + k * REFIT_BLOCK + (int)threadIdx.x;
-		if (i > hi) continue;
+	const int i = lo + t;
+	Climb left_over;
+	left_over.cur_ref = INT_MIN; left_over.l = left_over.r = 0;
+	if (i <= hi) {
 		BinNode cur = leaf_record(tris, (uint32_t)i, bp);
-		int cur_ref = ~i;
-		int node = parent_leaf[i];
-		int resume = -1;                        // node at which pass 2 continues for this thread, -1: none
-		while (node >= 0) {
-			// a Karras node is an end point of its own range: a node outside the tile has a range that leaves it
-			if (node < lo || node > hi || (s_arrive[node - lo] & 0x80000000u)) { resume = node; break; }
-			if (cur_ref >= 0) s_bin[cur_ref - lo] = cur;          // published before the arrival below (LDS is in order)
-			const uint32_t old = __hip_atomic_fetch_add(&s_arrive[node - lo], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (old == 0u) { cur_ref = -1 - n; break; }            // first arriver: the sibling's thread carries on
-			const int2 c = s_lr[node - lo];
-			const int sib = c.x == cur_ref ? c.y : c.x;
+		int cur_ref = ~i, L = i, R = i;
+		for (;;) {
+			if (L == 0 && R == n - 1) { *root = cur_ref; break; }          // the whole scene inside one tile
+			const int dl = s_delta[L - lo], dr = s_delta[R - lo + 1];
+			const bool go_right = L == 0 || (R != n - 1 && dr > dl);        // (never equal for the borders of a real subtree)
+			const int parent = go_right ? R : L - 1;
+			if (parent < lo || parent >= hi) {                               // its other child lies in a neighbouring tile
+				left_over.cur_ref = cur_ref; left_over.l = L; left_over.r = R;
+				break;
+			}
+			const int k = parent - lo;
+			if (go_right) { s_left[k] = cur_ref; s_rl[k] = L; } else { s_right[k] = cur_ref; s_rr[k] = R; }
+			// (cur, if it is an inner node, sits in s_bin[cur_ref - lo] already: LDS is in order, the arrival below publishes it)
+			const uint32_t old = __hip_atomic_fetch_add(&s_arrive[k], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (old == 0u) break;                                            // first arriver: the sibling's thread carries on
+			const int sib = go_right ? s_right[k] : s_left[k];
+			if (go_right) R = s_rr[k]; else L = s_rl[k];
 			const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : s_bin[sib - lo];
 			cur = combine_records(cur, other, bp);
-			cur_ref = node;
-			node = s_parent[node - lo];
+			cur_ref = parent;
+			s_bin[k] = cur;
 		}
-		if (cur_ref >= 0) s_bin[cur_ref - lo] = cur;              // finished subtree whose parent is outside the tile (or the root)
-		cont[i] = resume;
+		climbers[i] = left_over;
 	}
 	__syncthreads();
-	for (int k = threadIdx.x; k < REFIT_TILE; k += REFIT_BLOCK)
-		if (s_arrive[k] == 2u) bin[lo + k] = s_bin[k];
+	if (i < hi && s_arrive[t] == 2u) {
+		bin[i] = s_bin[t];
+		lr[i] = make_int2(s_left[t], s_right[t]);
+		range[i] = make_uint2((uint32_t)s_rl[t], (uint32_t)s_rr[t]);
+	} else if (i < hi && s_arrive[t] == 1u) {
+		// one child came, the other one's subtree reaches into a neighbouring tile and arrives in pass 2: hand the half that
+		// is here over in the form pass 2 uses (plain stores, the kernel boundary publishes them)
+		const bool left_here = s_left[t] != INT_MIN;
+		const int ref = left_here ? s_left[t] : s_right[t], end = left_here ? s_rl[t] : s_rr[t];
+		half[2 * (size_t)i + (left_here ? 0 : 1)] = ((unsigned long long)(uint32_t)ref << 32) | (uint32_t)end;
+		arrive[i] = 1u;
+	}
 }
 
-// Pass 2: the few nodes whose range crosses a tile boundary (about two per tile plus chains). The
-// hand-off of the first arriver's 32-byte record has to cross CUs and XCDs here (per-CU L1 and per-XCD
-// L2 are not coherent with each other): the record travels as four 8-byte device-scope atomics, which
-// execute at the memory side and are therefore coherent everywhere, and the arrival counter stays
-// relaxed. Records written by pass 1 are plain stores made visible by the kernel boundary.
+// Pass 2: the few nodes whose children lie in different tiles (about two per tile plus chains). The hand-off of the
+// first arriver's half -- its child reference, its range end and its 32-byte record -- has to cross CUs and XCDs here
+// (per-CU L1 and per-XCD L2 are not coherent with each other): everything travels as 8-byte device-scope atomics, which
+// execute at the memory side and are therefore coherent everywhere, and the arrival counter stays relaxed. Records
+// written by pass 1 are plain stores made visible by the kernel boundary.
 __device__ __forceinline__ void bin_store(BinNode *dst, const BinNode &v)
 {
 	unsigned long long *d = reinterpret_cast<unsigned long long *>(dst);
@@ -615,38 +607,57 @@ __device__ __forceinline__ void bin_store(BinNode *dst, const BinNode &v)
 	for (int k = 0; k < 4; k++) (void)__hip_atomic_exchange(d + k, sv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// a real read-modify-write (hipcc folds fetch_add(p, 0) into an sc1 load): compare-and-swap of a value with itself
+// returns the memory-side copy and never changes it
+__device__ __forceinline__ unsigned long long mem_load64(unsigned long long *p)
+{
+	unsigned long long expect = ~0ull;
+	(void)__hip_atomic_compare_exchange_strong(p, &expect, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return expect;
+}
+
 __device__ __forceinline__ BinNode bin_load(BinNode *src)
 {
 	BinNode v;
 	unsigned long long *d = reinterpret_cast<unsigned long long *>(src);
 	unsigned long long *dv = reinterpret_cast<unsigned long long *>(&v);
 #pragma unroll
-	for (int k = 0; k < 4; k++) {
-		// a real read-modify-write (hipcc folds fetch_add(p, 0) into an sc1 load): compare-and-swap of a
-		// value with itself returns the memory-side copy and never changes it
-		unsigned long long expect = ~0ull;
-		(void)__hip_atomic_compare_exchange_strong(d + k, &expect, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		dv[k] = expect;
-	}
+	for (int k = 0; k < 4; k++) dv[k] = mem_load64(d + k);
 	return v;
 }
 
-__global__ void k_refit_top(const DevTri *tris, int n, const int2 *lr, const int *parent_inner, const int *cont,
-	uint32_t *arrive, BinNode *bin, BuildParams bp)
+// half[node] = { left child | left range end , right child | right range end }: each half one 8-byte word
+__global__ void k_refit_top(const DevTri *tris, int n, const unsigned long long *keys, const Climb *climbers, unsigned long long *half,
+	uint32_t *arrive, BinNode *bin, int2 *lr, uint2 *range, int *root, BuildParams bp)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	int node = cont[i];
-	while (node >= 0) {
-		// every record this thread published is complete at the memory side before it announces itself
+	const Climb c = climbers[i];
+	if (c.cur_ref == INT_MIN) return;
+	int cur_ref = c.cur_ref, L = c.l, R = c.r;
+	BinNode cur = cur_ref < 0 ? leaf_record(tris, (uint32_t)~cur_ref, bp) : bin[cur_ref];      // finished by pass 1: plain load
+	for (;;) {
+		if (L == 0 && R == n - 1) { *root = cur_ref; return; }
+		const int dl = key_delta(keys, n, L - 1), dr = key_delta(keys, n, R);
+		const bool go_right = L == 0 || (R != n - 1 && dr > dl);
+		const int parent = go_right ? R : L - 1;
+		// this half: child reference and the range end it brings, then (inner nodes finished in THIS pass) its record
+		const unsigned long long mine = ((unsigned long long)(uint32_t)cur_ref << 32) | (uint32_t)(go_right ? L : R);
+		(void)__hip_atomic_exchange(half + 2 * (size_t)parent + (go_right ? 0 : 1), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// everything this thread published is complete at the memory side before it announces itself
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const uint32_t old = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t old = __hip_atomic_fetch_add(&arrive[parent], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (old == 0u) return;
-		const int2 c = lr[node];
-		const BinNode a = c.x < 0 ? leaf_record(tris, (uint32_t)~c.x, bp) : bin_load(&bin[c.x]);
-		const BinNode b = c.y < 0 ? leaf_record(tris, (uint32_t)~c.y, bp) : bin_load(&bin[c.y]);
-		bin_store(&bin[node], combine_records(a, b, bp));
-		node = parent_inner[node];
+		const unsigned long long theirs = mem_load64(half + 2 * (size_t)parent + (go_right ? 1 : 0));
+		const int sib = (int)(uint32_t)(theirs >> 32);
+		if (go_right) R = (int)(uint32_t)theirs; else L = (int)(uint32_t)theirs;
+		const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : bin_load(&bin[sib]);
+		cur = combine_records(cur, other, bp);
+		bin_store(&bin[parent], cur);
+		// topology of the finished node: read by the collapse only (later launches), plain stores
+		lr[parent] = go_right ? make_int2(cur_ref, sib) : make_int2(sib, cur_ref);
+		range[parent] = make_uint2((uint32_t)L, (uint32_t)R);
+		cur_ref = parent;
 	}
 }
 
@@ -901,19 +912,19 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs
 // that is already opened (dec/info valid) and hands over one that is opened too, block sums included. Launch 0 of a
 // build opens the root first.
 __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs B, LevelState *ring, uint32_t step, uint32_t max_levels,
-	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes)
+	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, const int *root)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
 	__shared__ int s_ref[COLLAPSE_SMALL * 4];
 	__shared__ uint32_t s_sums[COLLAPSE_SMALL * 4 / COLLAPSE_BLOCK];
 	LevelState L;
 	if (step == 0u) {
-		// level 0 is the root job (binary node 0), wide node 0
+		// level 0 is the root job (the binary node the refit pass ended at), wide node 0
 		L.count = 1u; L.base = 0u; L.level = 0u; L.total_nodes = 0u; L.depth = 0u; L.pad[0] = L.pad[1] = L.pad[2] = 0u;
 		if (threadIdx.x == 0) {
 			int4 d;
 			uint32_t inf;
-			B.sums[0] = collapse_open(0, 0u, lr, range, bin, tris, nodes, d, inf);
+			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, d, inf);
 			B.dec[0] = d;
 			B.info[0] = inf;
 		}
@@ -1302,7 +1313,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	need += padded((size_t)n * sizeof(InTri));                                       // decoded triangles in input order
 	need += 2 * padded((size_t)n * 8) + 2 * padded((size_t)n * 4);                  // keys a/b, vals a/b
 	need += padded(sort_words * 4) + padded(64) + padded(mesh_base.size() * 8);     // sort scratch, bounds, mesh_base
-	need += 2 * padded((size_t)n * 8) + 4 * padded((size_t)n * 4);                  // lr, range, parent_inner, parent_leaf, cont, arrive
+	need += 2 * padded((size_t)n * 8) + padded((size_t)n * 12) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(16);   // lr, range, climbers, halves, arrive, root
 	need += padded((size_t)n * sizeof(BinNode));                                    // bin
 	need += padded((size_t)n * 16) + 2 * padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);   // collapse: dec, info, jobs, block sums, ring
 	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case)
@@ -1437,19 +1448,21 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	}
 	stage("emit");
 
-	// ---- 6 karras, 7 refit ------------------------------------------------------------------
+	// ---- 6 + 7 tree topology and refit in one bottom-up pass ------------------------------------
 	int2 *d_lr = ar.take<int2>(n);
 	uint2 *d_range = ar.take<uint2>(n);
-	int *d_parent_inner = ar.take<int>(n), *d_parent_leaf = ar.take<int>(n), *d_cont = ar.take<int>(n);
+	Climb *d_climbers = ar.take<Climb>(n);
+	unsigned long long *d_half = ar.take<unsigned long long>(2 * (size_t)n);
 	uint32_t *d_arrive = ar.take<uint32_t>(n);
+	int *d_root = ar.take<int>(4);
 	BinNode *d_bin = ar.take<BinNode>(n);
 	if (hipMemsetAsync(d_arrive, 0, (size_t)n * 4, 0) != hipSuccess) return fail("memset");
-	hipLaunchKernelGGL(k_karras, dim3((n + 255u) / 256u), dim3(256), 0, 0, keys, (int)n, d_lr, d_range, d_parent_inner, d_parent_leaf);
-	stage("karras");
-	hipLaunchKernelGGL(k_refit_tile, dim3((n + REFIT_TILE - 1u) / REFIT_TILE), dim3(REFIT_BLOCK), 0, 0, d_tris, (int)n, d_lr, d_range,
-		d_parent_inner, d_parent_leaf, d_bin, d_cont, bp);
-	hipLaunchKernelGGL(k_refit_top, dim3((n + 255u) / 256u), dim3(256), 0, 0, d_tris, (int)n, d_lr, d_parent_inner, d_cont, d_arrive, d_bin, bp);
-	if (hipGetLastError() != hipSuccess) return fail("karras/refit");
+	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
+	hipLaunchKernelGGL(k_refit_tile, dim3((n + REFIT_TILE - 1u) / REFIT_TILE), dim3(REFIT_BLOCK), 0, 0, d_tris, (int)n, keys, d_lr, d_range,
+		d_bin, d_climbers, d_half, d_arrive, d_root, bp);
+	hipLaunchKernelGGL(k_refit_top, dim3((n + 255u) / 256u), dim3(256), 0, 0, d_tris, (int)n, keys, d_climbers, d_half, d_arrive, d_bin, d_lr, d_range,
+		d_root, bp);
+	if (hipGetLastError() != hipSuccess) return fail("refit");
 	stage("refit");
 
 	// ---- 8 collapse: one launch for the small levels at the top, two per big level, one for the tail ---------
@@ -1472,14 +1485,14 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		for (uint64_t c = COLLAPSE_SMALL; c < n; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp, d_root);
 			for (unsigned k = 0; k < big_levels; k++) {
 				// number the level of ring entry `step` (-> entry step + 1: the next level, not opened yet), then open that
 				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_nodes_tmp);
 				step++;
 				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
 			}
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp, d_root);
 			if (round == 0 && !node_mem) {
 				// While the GPU works through the levels: room for the final node arrays at the size 4-wide trees over n
 				// triangles usually have (0.47 n on the benchmark scenes); an exact allocation replaces it below if that is
