@@ -9,13 +9,13 @@
 // <= 63 triangles per leaf (rtk.c:188), and the blob format on export.
 //
 // Stages (all device kernels; the host only sequences launches):
-//   1 ingest     decode indices + positions of every mesh into staged triangles
-//   2 bounds     centroid bounds (wave shuffle -> LDS -> one atomic per block)
-//   3 morton     63-bit Morton key per triangle
+//   1 ingest     decode indices + positions of every mesh into 48-B staged triangles; centroid bounds in passing
+//   2 bounds     (separate pass only for host-decoded meshes)
+//   3 morton     63-bit Morton code per triangle; below 2^24 triangles its top 40 bits over the triangle's number
 //   4 sort       LSD radix sort, 8-bit digits, per-wave LDS histograms and counters
 //   5 emit       triangles gathered into Morton order = final 48 B leaf records
-//   6 karras     binary radix tree over the sorted keys (Karras 2012)
-//   7 refit      bottom-up AABBs + SAH leaf decision (agent-scope acq_rel arrival counters)
+//   6 + 7 refit  binary radix tree built bottom-up together with its AABBs and the SAH leaf decision: tile-local in
+//                LDS, then the nodes that cross tile borders with memory-side atomics
 //   8 collapse   breadth-first, level by level: binary tree -> 128 B 4-wide nodes
 #include "rtk_dev.h"
 
