@@ -724,7 +724,7 @@ __device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin, const Dev
 // Opens binary node b as wide node `node_index`: chooses its (up to four) children and writes the node except for the
 // numbers of the children that are wide nodes themselves. Returns how many those are.
 __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, const int2 *lr, const uint2 *range, const BinNode *bin,
-	DevTri *tris, DevNode *nodes, int4 &dec, uint32_t &info)
+	DevTri *tris, DevNode *nodes, uint32_t node_cap, int4 &dec, uint32_t &info)
 {
 	Cand c[4];
 	int nc;
@@ -794,9 +794,13 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 	}
 	// the boxes now (96 B = three whole 32-B sectors); the child words follow in ONE 32-B store when this node's level
 	// is numbered -- patching single words of a node written earlier made every patch a read-modify-write in memory
-	float4 *dst = reinterpret_cast<float4 *>(nodes + node_index);
+	// (node_cap: the collapse writes straight into the scene's node array, sized from an estimate; should a tree have more
+	// nodes than that, the writes beyond it are dropped and the host repeats the collapse into the workspace)
+	if (node_index < node_cap) {
+		float4 *dst = reinterpret_cast<float4 *>(nodes + node_index);
 #pragma unroll
-	for (int q = 0; q < 6; q++) dst[q] = rows[q];
+		for (int q = 0; q < 6; q++) dst[q] = rows[q];
+	}
 	for (int k = nc; k < 4; k++) r[k] = (int)RTK_REF_NONE;
 	dec = make_int4(r[0], r[1], r[2], r[3]);                      // final child words, except the slots in `mask`: binary references
 	info = (mask << 4) | (n_inner << 8);
@@ -806,7 +810,7 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 // Job `node_index`: its inner children get the numbers next_base + off, ...; the child words go out as one sector and
 // the children's binary references to next_jobs[off ...].
 __device__ __forceinline__ void collapse_number_children(uint32_t node_index, uint32_t next_base, uint32_t off, const int4 d,
-	uint32_t inf, DevNode *nodes, int *next_jobs)
+	uint32_t inf, DevNode *nodes, uint32_t node_cap, int *next_jobs)
 {
 	uint32_t ref[4] = { (uint32_t)d.x, (uint32_t)d.y, (uint32_t)d.z, (uint32_t)d.w };
 	const uint32_t mask = (inf >> 4) & 15u;
@@ -818,6 +822,7 @@ __device__ __forceinline__ void collapse_number_children(uint32_t node_index, ui
 		off++;
 	}
 	// child[4] and pad[4]: the last 32 bytes of the node, one sector
+	if (node_index >= node_cap) return;
 	uint4 *dst = reinterpret_cast<uint4 *>(&nodes[node_index].child[0]);
 	dst[0] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
 	dst[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -834,7 +839,7 @@ __device__ __forceinline__ LevelState next_level(const LevelState &L, uint32_t n
 }
 
 __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B, const LevelState *ring, uint32_t step, const int2 *lr, const uint2 *range,
-	const BinNode *bin, DevTri *tris, DevNode *nodes)
+	const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
 	const LevelState L = ring[step % COLLAPSE_RING];
@@ -845,7 +850,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B
 		if (j < count) {
 			int4 d;
 			uint32_t inf;
-			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, d, inf);
+			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, node_cap, d, inf);
 			B.dec[j] = d;
 			B.info[j] = inf;
 		}
@@ -876,7 +881,7 @@ __device__ __forceinline__ uint32_t block_range_sum(const uint32_t *a, uint32_t 
 	return r;
 }
 
-__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs B, LevelState *ring, uint32_t step, DevNode *nodes)
+__global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs B, LevelState *ring, uint32_t step, DevNode *nodes, uint32_t node_cap)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
 	__shared__ uint32_t s_r[COLLAPSE_BLOCK / 64];
@@ -900,7 +905,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs
 		off += inc - n_inner;
 		__syncthreads();
 		// (the job list is written over the one this level was opened from: nothing reads that any more)
-		if (j < count) collapse_number_children(base + j, next_base, off, d, inf, nodes, B.jobs);
+		if (j < count) collapse_number_children(base + j, next_base, off, d, inf, nodes, node_cap, B.jobs);
 		const uint32_t hi = vb + gridDim.x < nb ? vb + gridDim.x : nb;
 		before += block_range_sum(B.sums, vb, hi, s_r);
 	}
@@ -912,7 +917,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs
 // that is already opened (dec/info valid) and hands over one that is opened too, block sums included. Launch 0 of a
 // build opens the root first.
 __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs B, LevelState *ring, uint32_t step, uint32_t max_levels,
-	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, const int *root)
+	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
 	__shared__ int s_ref[COLLAPSE_SMALL * 4];
@@ -924,7 +929,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		if (threadIdx.x == 0) {
 			int4 d;
 			uint32_t inf;
-			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, d, inf);
+			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, node_cap, d, inf);
 			B.dec[0] = d;
 			B.info[0] = inf;
 		}
@@ -946,14 +951,14 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		uint32_t off = 0, total = 0;
 		for (uint32_t w = 0; w < COLLAPSE_SMALL / 64; w++) { if (w < wave) off += s_w[w]; total += s_w[w]; }
 		off += inc - n_inner;
-		if (j < L.count) collapse_number_children(L.base + j, L.base + L.count, off, d, inf, nodes, s_ref);
+		if (j < L.count) collapse_number_children(L.base + j, L.base + L.count, off, d, inf, nodes, node_cap, s_ref);
 		const LevelState N = next_level(L, total);
 		__syncthreads();
 		// ... and open the next level's (every dec/info of this level is in registers by now)
 		for (uint32_t i = threadIdx.x; i < total; i += COLLAPSE_SMALL) {
 			int4 d2;
 			uint32_t inf2;
-			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, d2, inf2);
+			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, node_cap, d2, inf2);
 			B.dec[i] = d2;
 			B.info[i] = inf2;
 			if (n2) atomicAdd(&s_sums[i / COLLAPSE_BLOCK], n2);
@@ -1475,9 +1480,17 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
 	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
 	LevelState h_state = {};
-	void *node_mem = nullptr;        // [DevNode x node_cap | DevNodeQ x node_cap], allocated while the collapse runs
-	size_t node_cap = 0;
-	{
+	// The node arrays of the scene, [DevNode x node_cap | DevNodeQ x node_cap], are allocated now -- the GPU is still busy
+	// with the refit -- at the size 4-wide trees over n triangles usually have (0.47 n on the benchmark scenes), and the
+	// collapse writes its nodes straight into them. A tree with more nodes than that drops the writes beyond the capacity
+	// (the kernels check) and is collapsed once more into the workspace, which holds n nodes.
+	void *node_mem = nullptr;
+	// (RTK_AMD_NODE_ESTIMATE_DIV: n / div + 16 instead, to drive the repeat path from tests)
+	const int est_div = getenv("RTK_AMD_NODE_ESTIMATE_DIV") ? atoi(getenv("RTK_AMD_NODE_ESTIMATE_DIV")) : 0;
+	size_t node_cap = est_div > 0 ? (size_t)n / (size_t)est_div + 16 : (size_t)n / 2 + 4096;
+	if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) { (void)hipGetLastError(); node_mem = nullptr; node_cap = 0; }
+	else ds->allocs.push_back(node_mem);      // owned by the scene from here on (error paths free it with the scene)
+	auto run_collapse = [&](DevNode *target, uint32_t cap) -> bool {
 		const unsigned big_blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
 		// levels with more than COLLAPSE_SMALL jobs in a balanced 4-wide tree over n triangles, plus slack; a tree that is
 		// deeper than that takes further rounds
@@ -1485,34 +1498,32 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		for (uint64_t c = COLLAPSE_SMALL; c < n; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp, d_root);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root);
 			for (unsigned k = 0; k < big_levels; k++) {
 				// number the level of ring entry `step` (-> entry step + 1: the next level, not opened yet), then open that
-				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_nodes_tmp);
+				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, target, cap);
 				step++;
-				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, d_nodes_tmp);
+				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, target, cap);
 			}
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, d_nodes_tmp, d_root);
-			if (round == 0 && !node_mem) {
-				// While the GPU works through the levels: room for the final node arrays at the size 4-wide trees over n
-				// triangles usually have (0.47 n on the benchmark scenes); an exact allocation replaces it below if that is
-				// not enough. hipMalloc of ~1 GB after the read-back cost more than a tenth of a 1M-triangle build.
-				node_cap = (size_t)n / 2 + 4096;
-				if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) { (void)hipGetLastError(); node_mem = nullptr; node_cap = 0; }
-				else ds->allocs.push_back(node_mem);      // owned by the scene from here on (error paths free it with the scene)
-			}
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root);
 			if (hipGetLastError() != hipSuccess ||
-				hipMemcpy(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return fail("collapse");
-			if (h_state.count == 0) break;
-			if (round > 4096) return fail("collapse did not terminate");
+				hipMemcpy(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return false;
+			if (h_state.count == 0) return true;
+			if (round > 4096) return false;
 			big_levels = 4;
 		}
+	};
+	bool in_place = node_mem != nullptr;
+	if (!run_collapse(in_place ? (DevNode *)node_mem : d_nodes_tmp, in_place ? (uint32_t)node_cap : n)) return fail("collapse");
+	if (in_place && h_state.total_nodes > node_cap) {
+		// the estimate was too small: once more, into the workspace; then an exact allocation
+		ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr;      // it was the last one pushed
+		in_place = false;
+		if (!run_collapse(d_nodes_tmp, n)) return fail("collapse");
 	}
 	const uint32_t total_nodes = h_state.total_nodes, depth = h_state.depth;
 	stage("collapse");
 
-	// the node arrays at their final place
-	if (node_mem && total_nodes > node_cap) { ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr; }   // it was the last one pushed
 	if (!node_mem) {
 		node_cap = total_nodes ? total_nodes : 1;
 		if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
@@ -1522,8 +1533,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	DevNode *d_nodes = (DevNode *)node_mem;
 	ds->view.nodes = d_nodes;
 	ds->view.num_nodes = total_nodes;
-	// one pass: exact nodes out of the workspace, compressed nodes beside them
-	if (rtk_quantize_nodes(ds, 0, d_nodes_tmp, (DevNodeQ *)(d_nodes + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+	// compressed nodes beside the exact ones (and, if the collapse had to go through the workspace, the exact ones out of it)
+	if (rtk_quantize_nodes(ds, 0, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
 	if (hipStreamSynchronize(0) != hipSuccess) return fail("sync");   // the workspace is handed back below
 
 	ds->view.tris = d_tris;

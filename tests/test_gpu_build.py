@@ -522,9 +522,11 @@ assert (gm == em).all() and (rec["prim"][gm] == eh["triangle_index"][em]).all() 
 print("OK", int(gm.sum()), c["content_hash"])
 ''' % ROOT
     outs = []
-    for env_extra in ({}, {"RTK_AMD_SORT_PACKED": "0", "RTK_AMD_SORT_FUSED_SCAN": "0"}):
+    # (third run: a node-count estimate that is far too small, so that the collapse is repeated into the workspace)
+    for env_extra in ({}, {"RTK_AMD_SORT_PACKED": "0", "RTK_AMD_SORT_FUSED_SCAN": "0"}, {"RTK_AMD_NODE_ESTIMATE_DIV": "16"}):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
         outs.append(r.stdout.split())
-    assert int(outs[0][1]) > 500 and outs[0][1] == outs[1][1]        # same hits either way
+    assert int(outs[0][1]) > 500 and outs[0][1] == outs[1][1] == outs[2][1]        # same hits either way
+    assert outs[0][2] == outs[2][2]                                                # and the very same tree after the repeat
