@@ -933,8 +933,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 			B.dec[0] = d;
 			B.info[0] = inf;
 		}
-		__threadfence();
-		__syncthreads();
+		__syncthreads();           // (workgroup scope is all that is needed: one workgroup, and the kernel boundary does the rest)
 	} else L = ring[step % COLLAPSE_RING];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	for (uint32_t it = 0; it < max_levels && L.count != 0u && L.count <= COLLAPSE_SMALL; it++) {
@@ -966,7 +965,9 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		__syncthreads();
 		if (threadIdx.x < (total + COLLAPSE_BLOCK - 1u) / COLLAPSE_BLOCK) B.sums[threadIdx.x] = s_sums[threadIdx.x];
 		L = N;
-		__threadfence();            // dec/info/sums of the next level are read by other threads of this workgroup, or by the next launch
+		// dec/info/sums of the next level are read by other threads of THIS workgroup (the barrier's workgroup-scope fence
+		// covers that) or by the next launch (the kernel boundary does). A device-scope __threadfence() here wrote back and
+		// invalidated the L2 at every level: ~25 us per level, a fifth of a 1M-triangle build.
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = L;
