@@ -679,7 +679,8 @@ __global__ void k_refit_top(const DevTri *tris, int n, const unsigned long long 
 // Level bookkeeping lives in device memory: launch number `step` reads ring entry step and writes entry step+1,
 // so nothing a running kernel reads is written by it. The host reads the ring once per round.
 #define COLLAPSE_BLOCK 256
-#define COLLAPSE_SMALL 1024
+#define COLLAPSE_SMALL 1024          // threads of k_collapse_small = children it opens per round
+#define COLLAPSE_SMALL_JOBS 64      // largest level it takes: its children (at most four each) are one round
 #define COLLAPSE_RING 64
 
 struct LevelState {
@@ -936,7 +937,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		__syncthreads();           // (workgroup scope is all that is needed: one workgroup, and the kernel boundary does the rest)
 	} else L = ring[step % COLLAPSE_RING];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	for (uint32_t it = 0; it < max_levels && L.count != 0u && L.count <= COLLAPSE_SMALL; it++) {
+	for (uint32_t it = 0; it < max_levels && L.count != 0u && L.count <= COLLAPSE_SMALL_JOBS; it++) {
 		// number this level's jobs ...
 		const uint32_t j = threadIdx.x;
 		const uint32_t inf = j < L.count ? B.info[j] : 0u;
@@ -1496,7 +1497,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		// levels with more than COLLAPSE_SMALL jobs in a balanced 4-wide tree over n triangles, plus slack; a tree that is
 		// deeper than that takes further rounds
 		unsigned big_levels = 2;
-		for (uint64_t c = COLLAPSE_SMALL; c < n; c *= 4) big_levels++;
+		for (uint64_t c = COLLAPSE_SMALL_JOBS; c < n; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
 			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root);
