@@ -1,5 +1,6 @@
 import csv,glob,sys
-f=sorted(glob.glob("gpurun_out/prof_build_%s/*/*_kernel_trace.csv"%sys.argv[1]))[-1]
+import os
+f=max(glob.glob("gpurun_out/prof_build_%s/*/*_kernel_trace.csv"%sys.argv[1]), key=os.path.getmtime)   # the newest run
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 names=[(r["Kernel_Name"][:58], (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3, int(r["Start_Timestamp"])) for r in rows]

@@ -169,6 +169,46 @@ static int hyb_rec(int lo, int hi) {
 	bin[id].l = l; bin[id].r = r; return id;
 }
 
+// LBVH above; below T prims the split position along the MORTON ORDER is chosen by the surface-area heuristic
+// (prefix / suffix box sweep): triangles stay where the sort put them, only the topology changes
+static int swp_build(int lo, int hi) {   // inclusive sorted range
+	if (lo == hi) return ~lo;
+	int n = hi - lo + 1;
+	std::vector<float> suf(n);
+	Box acc = pbox[hi]; suf[n - 1] = harea(acc);
+	for (int i = hi - 1; i > lo; i--) { acc = merge(acc, pbox[i]); suf[i - lo] = harea(acc); }
+	acc = pbox[lo]; float bestc = INFINITY; int best = lo;
+	for (int s = lo; s < hi; s++) {
+		if (s > lo) acc = merge(acc, pbox[s]);
+		float c = harea(acc) * (float)(s - lo + 1) + suf[s + 1 - lo] * (float)(hi - s);
+		if (c < bestc) { bestc = c; best = s; }
+	}
+	int id = (int)bin.size(); bin.push_back(Bin());
+	int l = swp_build(lo, best), r = swp_build(best + 1, hi);
+	bin[id].l = l; bin[id].r = r; return id;
+}
+static int mswp_rec(int lo, int hi) {
+	if (hi - lo + 1 <= HYB_T) return swp_build(lo, hi);
+	int split; uint64_t a = keys[lo], b = keys[hi];
+	if (a == b) split = (lo + hi) / 2;
+	else { int pre = __builtin_clzll(a ^ b); int s = lo; int step = hi - lo; do { step = (step + 1) >> 1; int ns = s + step; if (ns < hi) { uint64_t k = keys[ns]; int d = (k == a) ? 64 : __builtin_clzll(a ^ k); if (d > pre) s = ns; } } while (step > 1); split = s; }
+	int id = (int)bin.size(); bin.push_back(Bin());
+	int l = mswp_rec(lo, split), r = mswp_rec(split + 1, hi);
+	bin[id].l = l; bin[id].r = r; return id;
+}
+
+// fixed groups of T consecutive sorted prims rebuilt by SAH; above them the radix tree over the GROUP borders only
+// (what a bottom-up Apetrei climb gives when it starts from the groups instead of the leaves)
+static int grp_rec(int g0, int g1) {   // inclusive group range
+	if (g0 == g1) { int lo = g0 * HYB_T, hi = std::min((int)N, lo + HYB_T); std::vector<int> idx(hi - lo); for (int i = lo; i < hi; i++) idx[i - lo] = i; return sah_build(idx, 0, (int)idx.size()); }
+	// border after group g: similarity of keys[(g+1)*T-1] and keys[(g+1)*T]; split at the least similar border (first one on ties of equal keys -> middle)
+	int best = g0; int bestd = 1 << 30;
+	for (int g = g0; g < g1; g++) { uint64_t a = keys[(size_t)(g + 1) * HYB_T - 1], b = keys[(size_t)(g + 1) * HYB_T]; int d = a == b ? 64 + __builtin_clz((unsigned)(((g + 1) * HYB_T - 1) ^ ((g + 1) * HYB_T))) : __builtin_clzll(a ^ b); if (d < bestd) { bestd = d; best = g; } }
+	int id = (int)bin.size(); bin.push_back(Bin());
+	int l = grp_rec(g0, best), r = grp_rec(best + 1, g1);
+	bin[id].l = l; bin[id].r = r; return id;
+}
+
 // ---- SAH leaf decision (bottom-up): order-independent recursion
 static float CT = 1.0f, CN = 0.5f; static uint32_t MAXLEAF = 8;
 static float sah_rec(int id) {
@@ -306,6 +346,8 @@ int main(int argc, char **argv) {
 	if (builder == "lbvh") { bin.clear(); bin.reserve(N); root = lbvh_rec(0, (int)N - 1); refit_rec(root); }
 	else if (builder == "sah") { bin.clear(); bin.reserve(N); std::vector<int> idx(N); for (size_t i = 0; i < N; i++) idx[i] = (int)i; root = sah_build(idx, 0, (int)N); refit_rec(root); }
 	else if (builder == "hyb") { bin.clear(); bin.reserve(N); root = hyb_rec(0, (int)N - 1); refit_rec(root); }
+	else if (builder == "mswp") { bin.clear(); bin.reserve(N); root = mswp_rec(0, (int)N - 1); refit_rec(root); }
+	else if (builder == "grp") { bin.clear(); bin.reserve(N); root = grp_rec(0, (int)((N + HYB_T - 1) / HYB_T) - 1); refit_rec(root); }
 	else build_ploc(R);
 	double bt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	sah_rec(root);

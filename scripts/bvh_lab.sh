@@ -27,3 +27,9 @@ echo "# Morton key width: 63, 48, 42, 30 bits"
 ./lab -b lbvh -ks 0; ./lab -b lbvh -ks 15; ./lab -b lbvh -ks 21; ./lab -b lbvh -ks 33
 echo "# node width: 4, 6, 8 children (full distance sort), 8 with nearest-first-then-slot-order"
 ./lab -b lbvh -w 4; ./lab -b lbvh -w 6; ./lab -b lbvh -w 8; ./lab -b lbvh -w 8 -om 1
+echo "# SAH treelets: every maximal LBVH subtree of <= T triangles rebuilt by binned SAH (T = 8 .. 256; 8 bins at 64 and 32)"
+./lab -b hyb -T 8; ./lab -b hyb -T 16; ./lab -b hyb -T 32; ./lab -b hyb -T 64; ./lab -b hyb -T 64 -bins 8; ./lab -b hyb -T 32 -bins 8
+echo "# split position chosen by SAH along the Morton order (no re-ordering of triangles) inside subtrees of <= T"
+./lab -b mswp -T 16; ./lab -b mswp -T 64; ./lab -b mswp -T 256; ./lab -b mswp -T 1024
+echo "# fixed groups of T consecutive sorted triangles rebuilt by SAH, radix tree over the group borders above (groups straddle Morton jumps)"
+./lab -b grp -T 32 -bins 8; ./lab -b grp -T 64 -bins 8; ./lab -b grp -T 128 -bins 8
