@@ -150,7 +150,7 @@ __device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, const i32x8 &
 	const bool neg = sse_min(sse_min(u, v), w) < 0.0f;                           // rtk.c:340-342
 	const bool pos = sse_max(sse_max(u, v), w) > 0.0f;
 	// nobody in the packet passes the sign test: skip the divide and the rest (rtk.c:344 does the same per group)
-	if (__ballot(lanes && !(neg && pos)) == 0ull) return zero;
+	if (__builtin_amdgcn_ballot_w64(lanes && !(neg && pos)) == 0ull) return zero;
 	const float det = (u + v) + w;                                               // rtk.c:346-353
 	const float rcp = 1.0f / det;
 	float zz = u * z0;
@@ -240,7 +240,7 @@ __device__ __forceinline__ void pk_leaf(PkLane &L, bool live, const char *tris, 
 			else zero_seen |= pk_triangle<false, KZ>(L, live, ta, tb);
 		}
 		const bool redo = live && zero_seen;
-		if (__ballot(redo) != 0ull) {
+		if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
 			// an exact zero in a full group: those lanes redo the group in double (rtk.c:302-336)
 			if (redo) { L.t = sn_t; L.u = sn_u; L.v = sn_v; L.prim = sn_prim; }
 			for (uint32_t j = 0; j < m; j++) {
@@ -349,16 +349,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			fabsf(L.rdz) > 0x1p-100f && fabsf(L.rdz) < 0x1p100f;
 		const bool special = !(tame && L.tmin == L.tmin && L.tmax == L.tmax);
 		// wave-uniform facts about the packet
-		const unsigned long long m_alive = __ballot(alive);
-		const bool wave_fast = __ballot(alive && special) == 0ull;
-		const unsigned long long bsx = __ballot(alive && L.sx), bsy = __ballot(alive && L.sy), bsz = __ballot(alive && L.sz);
+		const unsigned long long m_alive = __builtin_amdgcn_ballot_w64(alive);
+		const bool wave_fast = __builtin_amdgcn_ballot_w64(alive && special) == 0ull;
+		const unsigned long long bsx = __builtin_amdgcn_ballot_w64(alive && L.sx), bsy = __builtin_amdgcn_ballot_w64(alive && L.sy), bsz = __builtin_amdgcn_ballot_w64(alive && L.sz);
 		const bool sign_uniform = (bsx == 0ull || bsx == m_alive) && (bsy == 0ull || bsy == m_alive) && (bsz == 0ull || bsz == m_alive);
 		const bool usx = sign_uniform && bsx != 0ull, usy = sign_uniform && bsy != 0ull, usz = sign_uniform && bsz != 0ull;
 		// byte offsets of the near / far plane rows inside a node (uniform signs), else (min, max)
 		const uint32_t onx = usx ? 16u : 0u, ofx = 16u - onx;
 		const uint32_t ony = 32u + (usy ? 16u : 0u), ofy = 80u - ony;
 		const uint32_t onz = 64u + (usz ? 16u : 0u), ofz = 144u - onz;
-		const unsigned long long bk0 = __ballot(alive && L.kz0), bk1 = __ballot(alive && L.kz1);
+		const unsigned long long bk0 = __builtin_amdgcn_ballot_w64(alive && L.kz0), bk1 = __builtin_amdgcn_ballot_w64(alive && L.kz1);
 		const bool kz_uniform = (bk0 == 0ull || bk0 == m_alive) && (bk1 == 0ull || bk1 == m_alive);
 		const uint32_t kzmode = !kz_uniform ? 3u : (bk0 != 0ull ? 0u : (bk1 != 0ull ? 1u : 2u));
 
@@ -366,13 +366,17 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 		uint32_t stack = 0;          // wave-uniform references, entry i in lane i
 		uint32_t sp = 0;             // wave-uniform
 		uint32_t top = 0;            // wave-uniform: root
-		bool live = alive;           // per lane
+		// which lanes take part in the node / leaf on top: kept as the wave's 64-bit mask (scalar registers) and turned into
+		// the per-lane condition where the vector side needs it -- as a per-lane bool carried around the loop hipcc
+		// rebuilt the mask from a 0/1 vector register at every vote (two vector instructions per ballot)
+		unsigned long long live_m = m_alive;
 		bool overflow = false;       // wave-uniform: a push did not fit (corrupted scene)
 
 		for (;;) {
 			bool pop = false;
 			if ((int32_t)top >= 0) {
 				// ---------------------------------------------------- node (wave-uniform)
+				const bool live = __builtin_amdgcn_inverse_ballot_w64(live_m);
 				PkNode nd;
 				s_load_node(nodes + (size_t)top * 128u, onx, ofx, ony, ofy, onz, ofz, nd);
 				if (COUNT && live) c_nodes++;
@@ -387,9 +391,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					else { pk_slab2<false, false, 0>(L, nd, live, pay[0], pay[1]); pk_slab2<false, false, 2>(L, nd, live, pay[2], pay[3]); }
 				}
 				// wave-level: which children does anybody enter
-				const bool e0 = pay[0] == pay[0], e1 = pay[1] == pay[1], e2 = pay[2] == pay[2], e3 = pay[3] == pay[3];
+				const unsigned long long m0 = __builtin_amdgcn_ballot_w64(pay[0] == pay[0]), m1 = __builtin_amdgcn_ballot_w64(pay[1] == pay[1]),
+					m2 = __builtin_amdgcn_ballot_w64(pay[2] == pay[2]), m3 = __builtin_amdgcn_ballot_w64(pay[3] == pay[3]);
 				// (a 4-bit set + s_bcnt1 on the scalar unit; summing four booleans went through VGPRs and readfirstlane: +2.3 %)
-				const uint32_t any_mask = (__ballot(e0) != 0ull ? 1u : 0u) | (__ballot(e1) != 0ull ? 2u : 0u) | (__ballot(e2) != 0ull ? 4u : 0u) | (__ballot(e3) != 0ull ? 8u : 0u);
+				// bit c = somebody enters child c. Written out: compare, then shift the bit in with the carry (eight scalar
+				// instructions; from the C expression hipcc made ~20, one of them a trip through a vector register)
+				uint32_t any_mask;
+				asm("s_cmp_lg_u64 %4, 0\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_lg_u64 %3, 0\n\ts_addc_u32 %0, %0, %0\n\t"
+					"s_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0"
+					: "=&s"(any_mask) : "s"(m0), "s"(m1), "s"(m2), "s"(m3) : "scc");
 				const bool a0 = (any_mask & 1u) != 0u, a1 = (any_mask & 2u) != 0u, a2 = (any_mask & 4u) != 0u, a3 = (any_mask & 8u) != 0u;
 				const uint32_t n_any = (uint32_t)__builtin_popcount(any_mask);
 				uint32_t ref[4] = { (uint32_t)nd.ch[0], (uint32_t)nd.ch[1], (uint32_t)nd.ch[2], (uint32_t)nd.ch[3] };
@@ -397,7 +407,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					pop = true;
 				} else if (n_any == 1u) {
 					// one child for the whole packet: a lane enters it iff it enters anything
-					live = e0 || e1 || e2 || e3;
+					live_m = m0 | m1 | m2 | m3;
 					top = a0 ? ref[0] : (a1 ? ref[1] : (a2 ? ref[2] : ref[3]));
 				} else if (n_any == 2u) {
 					// two children: pick them out (wave-uniform slot numbers), one comparison, one push
@@ -413,18 +423,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					case 10u: p0 = pay[1]; p1 = pay[3]; r0 = ref[1]; r1 = ref[3]; break;
 					default: p0 = pay[2]; p1 = pay[3]; r0 = ref[2]; r1 = ref[3]; break;
 					}
-					const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
+					const int lead = (int)__ffsll((long long)live_m) - 1;
 					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
 					const bool swap = k1 < k0;
 					const float pfar = swap ? p0 : p1, pnear = swap ? p1 : p0;
 					if (sp + 3u <= PK_LDS_STACK) PK_PUSH_LDS(pfar, swap ? r0 : r1);
 					else PK_PUSH(pfar, swap ? r0 : r1);
-					live = pnear == pnear;
+					live_m = __builtin_amdgcn_ballot_w64(pnear == pnear);
 					top = swap ? r1 : r0;
 				} else {
 					// order by the entry distance seen by the first live lane; its own misses (NaN) sort behind
 					// its hits, children nobody enters sort last. Keys per lane on the VALU, one readlane each.
-					const int lead = (int)__ffsll((long long)__ballot(live)) - 1;
+					const int lead = (int)__ffsll((long long)live_m) - 1;
 					int key[4];
 #pragma unroll
 					for (int c = 0; c < 4; c++) key[c] = __builtin_amdgcn_readlane(sort_key(pay[c]), lead);
@@ -445,12 +455,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 #pragma unroll
 						for (int i = 3; i >= 1; i--) if (n_any > (uint32_t)i) PK_PUSH(pay[i], ref[i]);
 					}
-					live = pay[0] == pay[0];
+					live_m = __builtin_amdgcn_ballot_w64(pay[0] == pay[0]);
 					top = ref[0];
 				}
 			} else {
 				// ---------------------------------------------------- leaf (wave-uniform)
 				const uint32_t slot0 = top & 0x7fffffffu;
+				const bool live = __builtin_amdgcn_inverse_ballot_w64(live_m);
 				if (COUNT && live) c_leaves++;
 				if (kzmode == 2u) pk_leaf<2, COUNT>(L, live, tris, slot0, lane, p.counter, c_tris);
 				else if (kzmode == 0u) pk_leaf<0, COUNT>(L, live, tris, slot0, lane, p.counter, c_tris);
@@ -468,8 +479,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					float te;
 					if (sp < PK_LDS_STACK) te = lds_read_f32((uint32_t)(size_t)&lds_t[sp][lane]);
 					else te = spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane];
-					live = alive && te <= L.t;
-					if (__ballot(live) != 0ull) {
+					live_m = __builtin_amdgcn_ballot_w64(te <= L.t) & m_alive;
+					if (live_m != 0ull) {
 						top = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
 						break;
 					}
