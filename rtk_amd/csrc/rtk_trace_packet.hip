@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	float (*lds_t)[64] = s_t[wave];
+	const uint32_t lds_base = (uint32_t)(size_t)&lds_t[0][lane];      // LDS byte address of this lane's column
 	const uint32_t glane = blockIdx.x * TRACE_BLOCK_THREADS + threadIdx.x;
 	float *const spill_t = reinterpret_cast<float *>(p.spill);
 	const char *const nodes = reinterpret_cast<const char *>(p.sc.nodes);
@@ -471,21 +472,41 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			}
 			if (pop) {
 				// pop until some lane still needs the entry (rtk.c:432, canonical: skip only if it starts BEHIND the hit)
-				bool done = false;
-				for (;;) {
-					if (sp == 0u) { done = true; break; }
+				bool found = false;
+				while (sp > PK_LDS_STACK) {                         // entries beyond the LDS part (deep trees only)
 					sp--;
-					// (written any other way hipcc merges the LDS and the spill read into one flat_load on a selected pointer)
-					float te;
-					if (sp < PK_LDS_STACK) te = lds_read_f32((uint32_t)(size_t)&lds_t[sp][lane]);
-					else te = spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane];
+					const float te = spill_t[(size_t)(sp - PK_LDS_STACK) * p.spill_stride + glane];
 					live_m = __builtin_amdgcn_ballot_w64(te <= L.t) & m_alive;
-					if (live_m != 0ull) {
-						top = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
-						break;
-					}
+					if (live_m != 0ull) { found = true; break; }
 				}
-				if (done) break;
+				if (!found) {
+					// The LDS part, written out: ten instructions per entry (hipcc's version of the same loop took ~25, with the
+					// stack pointer decremented on the vector unit and three flag masks per trip). Leaves with sp at the entry
+					// that was taken and `hit` = 1, or with sp = 0 and `hit` = 0.
+					uint32_t hit, off, addr;
+					float te;
+					asm volatile(
+						"s_mov_b32 %[hit], 0\n"
+						"1:\n\t"
+						"s_cmp_eq_u32 %[sp], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_sub_u32 %[sp], %[sp], 1\n\t"
+						"s_lshl_b32 %[off], %[sp], 8\n\t"
+						"v_add_u32_e32 %[addr], %[off], %[base]\n\t"
+						"ds_read_b32 %[te], %[addr]\n\t"
+						"s_waitcnt lgkmcnt(0)\n\t"
+						"v_cmp_le_f32_e32 vcc, %[te], %[t]\n\t"
+						"s_and_b64 %[live], vcc, %[alive]\n\t"
+						"s_cbranch_scc0 1b\n\t"
+						"s_mov_b32 %[hit], 1\n"
+						"2:"
+						: [sp] "+s"(sp), [hit] "=&s"(hit), [live] "=&s"(live_m), [off] "=&s"(off), [addr] "=&v"(addr), [te] "=&v"(te)
+						: [base] "v"(lds_base), [t] "v"(L.t), [alive] "s"(m_alive)
+						: "vcc", "scc", "memory");
+					found = hit != 0u;
+				}
+				if (!found) break;
+				top = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
 			}
 		}
 
