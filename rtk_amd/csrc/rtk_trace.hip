@@ -116,6 +116,15 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 			top = __uint_as_float(e_.x) > best_t ? RTK_REF_RETRY : e_.y;                                    \
 		}                                                                                                   \
 	} while (0)
+// One child of a node step: the lane enters it if its slab test passed and the slot is not empty; its key is the entry
+// distance (+inf otherwise) and nhit counts the children entered. The condition is kept as the wave's mask so that the
+// select reads it directly and the count is ONE add-with-carry (as a bool: a 0/1 select and an add).
+#define RTK_CHILD_HIT(slab_ok_, i_)                                                                                   \
+	do {                                                                                                              \
+		const unsigned long long hm_ = __builtin_amdgcn_ballot_w64(slab_ok_) & __builtin_amdgcn_ballot_w64(ref[i_] != RTK_REF_NONE); \
+		key[i_] = __builtin_amdgcn_inverse_ballot_w64(hm_) ? tn : __builtin_inff();                                   \
+		asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(nhit) : "s"(hm_) : "vcc");                                 \
+	} while (0)
 #define RTK_IS_LEAF(top_) ((top_) < RTK_REF_RETRY && (int32_t)(top_) < 0)
 
 #ifndef PL_MIN_WAVES
@@ -305,9 +314,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					const f32x2 pz = __builtin_elementwise_fma((f32x2){ ubyte_f32(wnz, i), ubyte_f32(wfz, i) }, (f32x2){ Sz, Sz }, (f32x2){ Anz, Afz });
 					const float tn = fmaxf(fmaxf(fmaxf(px.x, py.x), pz.x), tmin_ray);
 					const float tf = fminf(fminf(fminf(px.y, py.y), pz.y), best_t);
-					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
-					key[i] = h ? tn : __builtin_inff();
-					nhit += h ? 1u : 0u;
+					RTK_CHILD_HIT(tn <= tf, i);
 				}
 			} else {
 			const uint32_t a_node = top << 7;
@@ -325,9 +332,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 					const float az = (nz[i] - oz) * rdz, bz = (fz[i] - oz) * rdz;
 					const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), tmin_ray);
 					const float tf = fminf(fminf(fminf(bx, by), bz), best_t);
-					const bool h = (tn <= tf) && (ref[i] != RTK_REF_NONE);
-					key[i] = h ? tn : __builtin_inff();
-					nhit += h ? 1u : 0u;
+					RTK_CHILD_HIT(tn <= tf, i);
 				}
 			} else {
 #pragma unroll
