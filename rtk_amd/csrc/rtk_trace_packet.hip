@@ -78,8 +78,11 @@ __device__ __forceinline__ float lds_read_f32(uint32_t addr)
 
 __device__ __forceinline__ uint32_t stack_write(uint32_t stack, uint32_t value, uint32_t entry, uint32_t lane)
 {
-	// (v_writelane_b32 with an SGPR value AND an SGPR lane select breaks the one-SGPR constant-bus rule)
-	return lane == entry ? value : stack;
+	// (value and entry are wave-uniform: one v_writelane_b32 with the lane select in M0, not a compare and a select per lane)
+	// (no builtin for it in this compiler; M0 because a VALU instruction reads one scalar register besides M0. hipcc sets M0
+	// itself right before every use, so nothing of its own is live in it here)
+	asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack) : "s"(value), "s"(entry) : "m0");
+	return stack;
 }
 
 __device__ __forceinline__ int sort_key(float f)
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					case 10u: p0 = pay[1]; p1 = pay[3]; r0 = ref[1]; r1 = ref[3]; break;
 					default: p0 = pay[2]; p1 = pay[3]; r0 = ref[2]; r1 = ref[3]; break;
 					}
-					const int lead = (int)__ffsll((long long)live_m) - 1;
+					const int lead = __builtin_ctzll(live_m);          // (never empty here)
 					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
 					const bool swap = k1 < k0;
 					const float pfar = swap ? p0 : p1, pnear = swap ? p1 : p0;
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 				} else {
 					// order by the entry distance seen by the first live lane; its own misses (NaN) sort behind
 					// its hits, children nobody enters sort last. Keys per lane on the VALU, one readlane each.
-					const int lead = (int)__ffsll((long long)live_m) - 1;
+					const int lead = __builtin_ctzll(live_m);          // (never empty here)
 					int key[4];
 #pragma unroll
 					for (int c = 0; c < 4; c++) key[c] = __builtin_amdgcn_readlane(sort_key(pay[c]), lead);
