@@ -227,6 +227,7 @@ static int WIDTH = 4; static int ORDERMODE = 0;
 struct W { Box b[8]; int ref[8]; /* >=0 wide idx; <0: leaf id ~k */ int n; };
 struct Leaf { std::vector<uint32_t> prims; };
 static std::vector<W> wide; static std::vector<Leaf> leaves;
+static int COLLAPSE_CRIT = 0;  // which open child the greedy collapse opens next: 0 largest area, 1 area x count, 2 area saved, 3 count
 static int COLLAPSE_MODE = 0;   // 0 greedy largest area; 1 fixed two-level
 
 static void gather_prims(int ref, std::vector<uint32_t> &out) { if (ref < 0) { out.push_back(order[~ref]); return; } gather_prims(bin[ref].l, out); gather_prims(bin[ref].r, out); }
@@ -249,7 +250,12 @@ static void collapse() {
 			if (COLLAPSE_MODE == 0) {
 				for (int round = 0; round < WIDTH - 2; round++) {
 					int best = -1; float ba = 0;
-					for (int k = 0; k < nc; k++) if (ref_open(c[k])) { float a = harea(bin[c[k]].b); if (a > ba) { ba = a; best = k; } }
+					for (int k = 0; k < nc; k++) if (ref_open(c[k])) {
+						float a = harea(bin[c[k]].b);
+						if (COLLAPSE_CRIT == 1) a *= (float)bin[c[k]].cnt;                                   // area x triangles below
+						else if (COLLAPSE_CRIT == 2) a = a - 0.5f * (harea(ref_box(bin[c[k]].l)) + harea(ref_box(bin[c[k]].r)));   // what opening saves
+						else if (COLLAPSE_CRIT == 3) a = (float)bin[c[k]].cnt;                               // most triangles below
+						if (a > ba) { ba = a; best = k; } }
 					if (best < 0) break;
 					int o = c[best]; c[best] = bin[o].l; c[nc++] = bin[o].r;
 				}
@@ -333,6 +339,7 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-cn")) CN = atof(argv[++i]);
 		else if (!strcmp(argv[i], "-ml")) MAXLEAF = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-cm")) COLLAPSE_MODE = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-cc")) COLLAPSE_CRIT = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-t")) trisf = argv[++i];
 		else if (!strcmp(argv[i], "-T")) HYB_T = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-ks")) KEYSHIFT = atoi(argv[++i]);

@@ -33,3 +33,5 @@ echo "# split position chosen by SAH along the Morton order (no re-ordering of t
 ./lab -b mswp -T 16; ./lab -b mswp -T 64; ./lab -b mswp -T 256; ./lab -b mswp -T 1024
 echo "# fixed groups of T consecutive sorted triangles rebuilt by SAH, radix tree over the group borders above (groups straddle Morton jumps)"
 ./lab -b grp -T 32 -bins 8; ./lab -b grp -T 64 -bins 8; ./lab -b grp -T 128 -bins 8
+echo "# which open child the greedy collapse opens next: area x triangle count, area saved by opening, triangle count (largest area = the first line of this log)"
+./lab -b lbvh -cc 1; ./lab -b lbvh -cc 2; ./lab -b lbvh -cc 3
