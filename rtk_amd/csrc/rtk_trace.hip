@@ -264,20 +264,27 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			}
 		}
 
+		// the active lanes as a wave mask in SCALAR registers (first-lane reads: left to itself hipcc keeps this loop-carried
+		// value in a vector register pair): the votes below are votes on plain comparisons ANDed with it on the scalar unit
+		// -- a vote on `active && ...` rebuilds the mask from a 0/1 vector register, two vector instructions each
+		const unsigned long long m_act_ = __builtin_amdgcn_ballot_w64(active);
+		const unsigned long long m_active = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m_act_ >> 32)) << 32) |
+			(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m_act_);
 		// ---------------------------------------------------------------- inner nodes
 		for (;;) {
 			// Lanes that reached a leaf wait here for the others. When only a few lanes are
 			// still descending and leaves are waiting, go and do the leaves first.
 			const bool retry = active && top == RTK_REF_RETRY;
 			if (retry) RTK_POP();
-			const bool want_node = active && (int32_t)top >= 0;
-			const unsigned long long m_node = __builtin_amdgcn_ballot_w64(want_node);
+			const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t)top >= 0) & m_active;
+			const bool want_node = __builtin_amdgcn_inverse_ballot_w64(m_node);
 			if (m_node == 0ull) {
-				if (__builtin_amdgcn_ballot_w64(active && top == RTK_REF_RETRY) != 0ull) continue;   // somebody is still popping
+				if ((__builtin_amdgcn_ballot_w64(top == RTK_REF_RETRY) & m_active) != 0ull) continue;   // somebody is still popping
 				break;
 			}
 			// (lanes still popping are not counted as descending: counting them was 1 % slower)
-			if ((uint32_t)__popcll(m_node) < p.node_exit && __builtin_amdgcn_ballot_w64(active && RTK_IS_LEAF(top)) != 0ull) break;
+			// (RTK_IS_LEAF as one signed comparison: sign bit set and below RTK_REF_RETRY = -2)
+			if ((uint32_t)__popcll(m_node) < p.node_exit && (__builtin_amdgcn_ballot_w64((int32_t)top < (int32_t)RTK_REF_RETRY) & m_active) != 0ull) break;
 			if (COUNT) w_node_steps++;
 			if (!want_node) continue;
 			uint32_t ref[4];
