@@ -83,6 +83,9 @@ def limiter_from_pmc(pj):
     if m("SQ_ACTIVE_INST_VALU") and ns:
         # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs (MI355X_MICROARCH.md, cycle constants)
         out["valu_busy"] = round(m("SQ_ACTIVE_INST_VALU") * 4.0 / (SIMDS * ns * CLOCK_GHZ), 3)
+    if m("SQ_INSTS_SALU") and ns:
+        # one scalar ALU per CU, shared by its four SIMDs, one instruction per cycle
+        out["salu_issue"] = round(m("SQ_INSTS_SALU") / (SIMDS / 4.0 * ns * CLOCK_GHZ), 3)
     if m("SQ_THREAD_CYCLES_VALU") and m("SQ_ACTIVE_INST_VALU"):
         out["valu_lane_utilisation"] = round(m("SQ_THREAD_CYCLES_VALU") / (64.0 * m("SQ_ACTIVE_INST_VALU")), 3)
     if m("SQ_WAIT_ANY") and m("SQ_WAVE_CYCLES"):
@@ -399,7 +402,8 @@ def main():
                      "kernel_ms": round(k_ms, 4),
                      "limiter": dict(limiter, fabric_tb_s=round(traffic / pj["kernel_trace"]["average_ns"] / 1e3, 2) if traffic else None,
                                      note=("VALU pipes busy `valu_busy` of the traversal kernel's time at `valu_lane_utilisation` "
-                                           "(SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * time * %.1f GHz), SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)), "
+                                           "(SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * time * %.1f GHz), SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)); "
+                                           "`salu_issue` = SQ_INSTS_SALU / (256 CUs * time * clock): scalar instructions per cycle of a CU's one scalar unit; "
                                            "`fabric_tb_s` = traffic / kernel time against ~6.3 TB/s achievable HBM and ~8.6 TB/s MALL gather rate; "
                                            "counters from %s" % (CLOCK_GHZ, traffic_src))) if limiter else None,
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
