@@ -123,6 +123,7 @@ static void build_ploc(int R) {
 
 
 // ---- binned SAH top-down over an arbitrary list of sorted indices (idx values index pbox/order)
+static int BIN_OVER_BOX = 0;
 static int SAH_BINS = 32; static int SAH_LEAF = 1;
 static int sah_build(std::vector<int> &idx, int lo, int hi) {   // [lo,hi)
 	int n = hi - lo;
@@ -130,8 +131,9 @@ static int sah_build(std::vector<int> &idx, int lo, int hi) {   // [lo,hi)
 	Box cb; for (int k = 0; k < 3; k++) { cb.mn[k] = 1e30f; cb.mx[k] = -1e30f; }
 	Box nb = cb;
 	for (int i = lo; i < hi; i++) { const Box &b = pbox[idx[i]]; nb = merge(nb, b); for (int k = 0; k < 3; k++) { float c = b.mn[k] + b.mx[k]; cb.mn[k] = std::min(cb.mn[k], c); cb.mx[k] = std::max(cb.mx[k], c); } }
+	if (BIN_OVER_BOX) { for (int k = 0; k < 3; k++) { cb.mn[k] = 2 * nb.mn[k]; cb.mx[k] = 2 * nb.mx[k]; } }   // bin over the node's box instead of its centroid bounds
 	float bestc = INFINITY; int besta = -1, bestb = -1;
-	const int NB = SAH_BINS;
+	const int NB = SAH_BINS < 0 ? std::min(-SAH_BINS, n) : SAH_BINS;      // negative: at most that many, never more bins than items
 	for (int a = 0; a < 3; a++) {
 		float ext = cb.mx[a] - cb.mn[a]; if (!(ext > 0)) continue;
 		std::vector<Box> bb(NB); std::vector<int> bc(NB, 0);
@@ -339,6 +341,7 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-cn")) CN = atof(argv[++i]);
 		else if (!strcmp(argv[i], "-ml")) MAXLEAF = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-cm")) COLLAPSE_MODE = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-bob")) BIN_OVER_BOX = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-cc")) COLLAPSE_CRIT = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-t")) trisf = argv[++i];
 		else if (!strcmp(argv[i], "-T")) HYB_T = atoi(argv[++i]);

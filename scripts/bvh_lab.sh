@@ -35,3 +35,5 @@ echo "# fixed groups of T consecutive sorted triangles rebuilt by SAH, radix tre
 ./lab -b grp -T 32 -bins 8; ./lab -b grp -T 64 -bins 8; ./lab -b grp -T 128 -bins 8
 echo "# which open child the greedy collapse opens next: area x triangle count, area saved by opening, triangle count (largest area = the first line of this log)"
 ./lab -b lbvh -cc 1; ./lab -b lbvh -cc 2; ./lab -b lbvh -cc 3
+echo "# what one wave could do for a 64-triangle treelet: at most 8 bins and never more than items; the same binned over the node's box instead of its centroid bounds"
+./lab -b hyb -T 64 -bins -8; ./lab -b hyb -T 64 -bins -8 -bob 1
