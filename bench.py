@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="coherent", choices=["coherent", "incoherent", "shadow"])
-    ap.add_argument("--bvh", default="device", choices=["device", "oracle-blob"],
+    ap.add_argument("--bvh", default="device", choices=["device", "oracle-blob", "cpu-sah"],
                     help="device = GPU LBVH build (product path); oracle-blob = upload a blob built by the CPU oracle (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -189,6 +189,24 @@ def main():
     elif args.bvh == "device":
         ds = api.DeviceScene.build([dict(positions=tris)])
         bvh_kind = "gpu-lbvh"
+    elif args.bvh == "cpu-sah":
+        # tree-quality experiment: the product's own task-graph CPU builder (binned SAH, top down) builds
+        # the blob, the GPU traces it. RTK_AMD_CPU_SAH_SPLIT_COST=0.5 RTK_AMD_CPU_LEAF_MIN=1 give the one-triangle leaves
+        # of the device build, so that only the topology differs.
+        import ctypes as C
+        from rtk_amd.types import MeshSet, SceneHeader
+        L = api.lib()
+        ms = MeshSet([dict(positions=tris)])
+        L.rtk_amd_set_builder(1)
+        p = L.rtk_build_scene(C.byref(ms.desc))
+        L.rtk_amd_set_builder(0)
+        if not p:
+            raise RuntimeError("cpu builder: " + str(api.last_error()))
+        hdr = SceneHeader.from_address(p)
+        blob_bytes = np.ctypeslib.as_array((C.c_uint8 * hdr.size_in_bytes).from_address(p)).copy()
+        L.rtk_free_scene(p)
+        ds = api.DeviceScene.upload(blob_bytes)
+        bvh_kind = "cpu-task-graph-sah-blob-upload (split cost %s, leaf min %s)" % (os.environ.get("RTK_AMD_CPU_SAH_SPLIT_COST", "1"), os.environ.get("RTK_AMD_CPU_LEAF_MIN", "4"))
     else:
         from oracle import pyoracle
         oracle_blob = pyoracle.build_scene([dict(positions=tris)])

@@ -40,13 +40,23 @@ namespace {
 const size_t MAX_RANGES = 128;            // RTK_MAX_CONCURRENT_TASKS, rtk.c:590-592
 const size_t MIN_RANGE = 1024;            // rtk.c:1370
 const int SAH_BINS = 32;                  // RTK_BUILD_SPLITS, rtk.c:586-588
-const size_t LEAF_MIN = 4;                // RTK_BVH_LEAF_MIN_ITEMS, rtk.c:6
 const size_t LEAF_MAX = 63;               // 6-bit count in the leaf header (rtk.c:188; B7)
 const uint32_t MAX_DEPTH = 64;            // RTK_BVH_MAX_DEPTH, rtk.c:5
 const size_t GROUP_MAX = 256;             // RTK_VERTEX_SET_MAX_SIZE, rtk.c:1186
 const size_t INLINE_ITEMS = 4096;         // subtrees up to this size are built inside their task
 const size_t FINALIZE_SPLIT = 2048;       // rtk.c:1492: finalize recurses into tasks above this size
-const float SAH_ITEM_COST = 1.0f, SAH_SPLIT_COST = 1.0f;
+// cost constants of rtk.c:931-949 (1 / 1 as the oracle uses). RTK_AMD_CPU_SAH_SPLIT_COST /
+// RTK_AMD_CPU_SAH_ITEM_COST change them for experiments (a split cost of 0.5 gives the one-triangle leaves of the device
+// build: bench.py --bvh cpu-sah); read once per process.
+float sah_env(const char *name, float dflt)
+{
+	const char *v = getenv(name);
+	if (!v || !*v) return dflt;
+	const float f = (float)atof(v);
+	return f > 0.0f ? f : dflt;
+}
+const size_t LEAF_MIN = (size_t)sah_env("RTK_AMD_CPU_LEAF_MIN", 4.0f);       // RTK_BVH_LEAF_MIN_ITEMS, rtk.c:6 (1: split down to single triangles)
+const float SAH_ITEM_COST = sah_env("RTK_AMD_CPU_SAH_ITEM_COST", 1.0f), SAH_SPLIT_COST = sah_env("RTK_AMD_CPU_SAH_SPLIT_COST", 1.0f);
 
 struct Item {
 	float mn[3], mx[3];
