@@ -3,7 +3,7 @@
 # and wave-level steps per 64 rays.  bash scripts/tree_quality_gpu.sh > profiles/r02_tree_quality_gpu.log
 export RTK_AMD_CPU_SAH_SPLIT_COST=0.5 RTK_AMD_CPU_LEAF_MIN=1
 for wl in coherent incoherent shadow; do
-  for bvh in device cpu-sah; do
+  for bvh in device cpu-sah oracle-blob; do      # oracle-blob: the CPU oracle's SAH tree as it is (leaves of ~3 triangles)
     timeout -k 10 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $wl --bvh $bvh 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
