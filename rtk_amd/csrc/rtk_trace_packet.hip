@@ -28,7 +28,7 @@
 #define PK_LDS_STACK 16            // per-lane entry distances held in LDS
 #define PK_WAVE_STACK 64           // wave-uniform references held in one VGPR
 #ifndef PK_MIN_WAVES
-#define PK_MIN_WAVES 6             // waves per SIMD the register allocator must leave room for: 80 VGPRs (5 spilled to scratch, read back once per tile), measured +5 % over 5
+#define PK_MIN_WAVES 7             // waves per SIMD the register allocator must leave room for: 69 VGPRs without the SLP vectoriser (Makefile), so 7 fit (72): +4.5 % over 6; 8 (64 VGPRs, spills) is back at 6's rate
 #endif
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));

@@ -4,7 +4,10 @@
 
 #include "rtk_dev.h"
 
-#define LDS_STACK 16           // entries per lane held in LDS
+#ifndef LDS_STACK
+#define LDS_STACK 15           // entries per lane held in LDS: 30 KB per workgroup, so that FIVE workgroups share a CU's 160 KB (with 16
+                               // entries = 32 KB only four are placed: -5 % on incoherent rays, -4 % on shadow rays; 14 and 13 spill more)
+#endif
 #define TRACE_WAVES_PER_BLOCK 4
 #define TRACE_BLOCK_THREADS (64 * TRACE_WAVES_PER_BLOCK)
 #define WAVES_PER_BLOCK TRACE_WAVES_PER_BLOCK
