@@ -253,3 +253,42 @@ def test_task_graph_builder_survives_degenerate_input(cpu_builder, oracle, name)
     assert oracle.validate_blob(blob)[0] == 0, name
     rays = synth.rays_config1(512)
     oracle.trace(blob, rays)          # terminates
+
+
+def test_cost_knobs_change_the_leaves_not_the_hits(oracle):
+    """RTK_AMD_CPU_SAH_SPLIT_COST / RTK_AMD_CPU_LEAF_MIN (read once per process: a child process) make the task-graph builder
+    split down to single triangles -- the tree bench.py --bvh cpu-sah uploads -- and the oracle finds the same hits in it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from rtk_amd import api, synth
+from rtk_amd.types import MeshSet, SceneHeader
+from oracle import pyoracle
+tris = synth.triangle_soup(4000, 0.05, 3)
+L = api.lib(); ms = MeshSet([dict(positions=tris)])
+L.rtk_amd_set_builder(1); p = L.rtk_build_scene(C.byref(ms.desc)); L.rtk_amd_set_builder(0)
+assert p, api.last_error()
+hdr = SceneHeader.from_address(p)
+blob = pyoracle.Blob(np.ctypeslib.as_array((C.c_uint8 * hdr.size_in_bytes).from_address(p)).copy())
+rc, counts = pyoracle.validate_blob(blob)
+hits, mask = pyoracle.trace(blob, synth.rays_config1(2048))
+print(rc, counts["leaves"], counts["tris"], int(mask.sum()), int(hits["triangle_index"][mask].astype(np.int64).sum()), float(hits["t"][mask].astype(np.float64).sum()))
+""" % root
+    outs = []
+    for env in ({}, {"RTK_AMD_CPU_SAH_SPLIT_COST": "0.5", "RTK_AMD_CPU_LEAF_MIN": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    (rc0, leaves0, tris0, *hits0), (rc1, leaves1, tris1, *hits1) = outs
+    assert rc0 == "0" and rc1 == "0" and tris0 == tris1 == "4000"
+    assert int(leaves1) > 0.95 * 4000 > int(leaves0)            # single-triangle leaves with the knobs, ~3 per leaf without
+    # the same triangles from either tree; t differs in its last bits where a triangle sits in a different group of four
+    # (rtk.c:302-336 computes partial groups in double precision)
+    assert hits0[:2] == hits1[:2]
+    assert abs(float(hits0[2]) - float(hits1[2])) <= 1e-6 * abs(float(hits0[2]))
