@@ -23,6 +23,19 @@
 #include <mutex>
 
 __device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+// rays are read once and hit records written once: streamed past the caches ("nt") so that they do not push the BVH out of the L2
+__device__ __forceinline__ float4 ld_f4_stream(const char *p)
+{
+	const f32x4_ v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ *>(p));
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_f4_stream(void *p, float x, float y, float z, float w)
+{
+	f32x4_ v;
+	v.x = x; v.y = y; v.z = z; v.w = w;
+	__builtin_nontemporal_store(v, reinterpret_cast<f32x4_ *>(p));
+}
 __device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -215,8 +228,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 				const uint32_t take = n_idle < avail ? n_idle : (uint32_t)avail;
 				if (!active && rank < take) {
 					ray_index = p.perm ? (uint32_t)p.perm[w_next + rank] : (uint32_t)map_index(w_next + rank, p.image_w, p.image_h, p.tile_blocks);   // perm: sort words, ray number in the low half
-					const float4 r0 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index));
-					const float4 r1 = ld_f4(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
+					const float4 r0 = ld_f4_stream(reinterpret_cast<const char *>(p.rays + ray_index));
+					const float4 r1 = ld_f4_stream(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
 					ox = r0.x; oy = r0.y; oz = r0.z;
 					const float dx = r0.w, dy = r1.x, dz = r1.y;
 					tmin_ray = r1.z; tmax_ray = r1.w;
@@ -536,8 +549,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			} else {
 				rtk_hit_record r;
 				r.t = best_t; r.u = best_u; r.v = best_v; r.prim = best_prim;
-				*reinterpret_cast<float4 *>(p.hits + ray_index) =
-					make_float4(r.t, r.u, r.v, __uint_as_float(r.prim));
+				st_f4_stream(p.hits + ray_index, r.t, r.u, r.v, __uint_as_float(r.prim));
 			}
 			if (COUNT) {
 				atomicAdd(p.counter + 1, 1ull);

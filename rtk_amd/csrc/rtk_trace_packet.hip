@@ -34,6 +34,7 @@
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float asf(int v) { return __int_as_float(v); }
 
@@ -322,8 +323,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 
 		PkLane L;
 		{
-			const float4 r0 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.rays + ray_index));
-			const float4 r1 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.rays + ray_index) + 16);
+			// (rays and hit records are streamed past the caches, "nt": read / written once, and the L2 is wanted for the BVH)
+			const f32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.rays + ray_index)));
+			const f32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.rays + ray_index) + 16));
 			L.ox = r0.x; L.oy = r0.y; L.oz = r0.z;
 			const float dx = r0.w, dy = r1.x, dz = r1.y;
 			L.tmin = r1.z; L.tmax = r1.w;
@@ -515,7 +517,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 
 		if (overflow && lane == 0) p.counter[RTK_ERROR_WORD] = 1ull;
 		if (alive) {
-			*reinterpret_cast<float4 *>(p.hits + ray_index) = make_float4(L.t, L.u, L.v, __uint_as_float(L.prim));
+			f32x4 rec;
+			rec.x = L.t; rec.y = L.u; rec.z = L.v; rec.w = __uint_as_float(L.prim);
+			__builtin_nontemporal_store(rec, reinterpret_cast<f32x4 *>(p.hits + ray_index));
 			if (COUNT) {
 				atomicAdd(p.counter + 1, 1ull);
 				atomicAdd(p.counter + 2, (unsigned long long)c_nodes);
