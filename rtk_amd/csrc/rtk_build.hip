@@ -322,10 +322,12 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 	uint32_t shift, uint32_t num_units, const uint32_t *hist, unsigned long long *keys_out, uint32_t *vals_out,
 	const uint32_t *scan_sums, uint32_t scan_blocks)
 {
-	__shared__ uint32_t s_bp[SORT_BLOCK];                    // scan_sums != NULL: exclusive prefix of the scan blocks' totals
+	// (LDS: 36.9 KB without values -- 16-bit counts, s_bp inside s_key -- so that four workgroups fit a CU with room to spare; with
+	// 39.9 KB the four of them came to 159.8 of the CU's 160 KB. No measurable difference in the pass time either way.)
 	__shared__ unsigned long long s_key[SORT_TILE];          // 32 KB
+	uint32_t *const s_bp = reinterpret_cast<uint32_t *>(s_key);   // scan_sums != NULL: exclusive prefix of the scan blocks' totals; used before s_key is
 	__shared__ uint32_t s_val[SORT_TILE];                    // 16 KB
-	__shared__ uint32_t s_cnt[SORT_BLOCK / 64][256];         // per wave: running count, then prefix over earlier waves
+	__shared__ uint16_t s_cnt[SORT_BLOCK / 64][256];         // per wave: running count (<= 1024), then prefix over earlier waves (<= 4096)
 	__shared__ uint32_t s_start[256];                        // first tile position of each digit
 	__shared__ uint32_t s_global[256];                       // first output position of this tile's keys of each digit
 	__shared__ uint32_t s_wsum[SORT_BLOCK / 64];
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 			const uint32_t r = (uint32_t)__popcll(same & lt_mask);
 			const uint32_t before = s_cnt[wave][d];            // every lane reads before any leader writes (wave program order)
 			rnk[c] = before + r;
-			if (r == 0u) s_cnt[wave][d] = before + (uint32_t)__popcll(same);
+			if (r == 0u) s_cnt[wave][d] = (uint16_t)(before + (uint32_t)__popcll(same));
 		}
 	}
 	__syncthreads();
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 	{
 		const uint32_t d = threadIdx.x;
 		uint32_t run = 0;
-		for (uint32_t w = 0; w < SORT_BLOCK / 64; w++) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = run; run += c; }
+		for (uint32_t w = 0; w < SORT_BLOCK / 64; w++) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = (uint16_t)run; run += c; }
 		// exclusive scan of the 256 digit totals
 		uint32_t inc = run;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
