@@ -44,7 +44,7 @@ def log(*a):
 
 
 KERNEL_SOURCES = ["rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h",
-                  "rtk_amd/csrc/rtk_dev.h"]
+                  "rtk_amd/csrc/rtk_dev.h", "rtk_amd/csrc/Makefile"]      # (the Makefile: compiler switches change the kernels too)
 CLOCK_GHZ = 2.4                 # MI355X max engine clock (MI355X_MICROARCH.md); the clock held under load is lower
 SIMDS = 256 * 4
 

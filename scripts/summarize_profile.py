@@ -27,7 +27,7 @@ def main():
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h", "rtk_amd/csrc/rtk_dev.h"):
+    for f in ("rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h", "rtk_amd/csrc/rtk_dev.h", "rtk_amd/csrc/Makefile"):
         h.update(open(os.path.join(root, f), "rb").read())
     out["kernel_source_sha16"] = h.hexdigest()[:16]
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
