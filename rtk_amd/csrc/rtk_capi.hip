@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 
@@ -242,6 +243,9 @@ struct HostCtx {
 	rtk_hit *h_hits = nullptr, *d_hits = nullptr;
 	uint8_t *h_mask = nullptr, *d_mask = nullptr;
 	rtk_hit_record *h_after = nullptr, *d_after = nullptr;
+	unsigned long long *h_status = nullptr;    // pinned: the expand kernel of a zero-copy piece mirrors the launch-error word here
+	bool status_mirrored = false;              // ... for the piece in flight
+	uint32_t ticket = 0, ticket_in_flight = 0; // pieces of one workgroup (<= 256 rays) are waited for by polling h_status for their ticket
 	// candidate lists for host-callback filters: CAND_SLOTS records in all, k = CAND_SLOTS / rays of them per ray
 	rtk_hit_record *h_cand = nullptr, *d_cand = nullptr;
 	rtk_hit *h_cand_hits = nullptr, *d_cand_hits = nullptr;
@@ -289,7 +293,7 @@ struct HostCtx {
 		size_t want = 64;
 		while (want < n) want <<= 1;
 		const size_t per_ray = sizeof(rtk_ray) + 2 * sizeof(rtk_hit_record) + sizeof(rtk_hit) + 4 /* mask, kept 4-aligned */;
-		if (hipHostMalloc((void **)&pinned, want * per_ray, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&dev, want * per_ray) != hipSuccess) {
+		if (hipHostMalloc((void **)&pinned, want * per_ray + 64, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&dev, want * per_ray + 64) != hipSuccess) {
 			rtk_set_error("rtk_trace_rays: staging allocation failed (%zu rays): %s", want, hipGetErrorString(hipGetLastError()));
 			release();
 			return false;
@@ -303,7 +307,8 @@ struct HostCtx {
 			rtk_hit_record *aft = (rtk_hit_record *)take(want * sizeof(rtk_hit_record));
 			rtk_hit *hh = (rtk_hit *)take(want * sizeof(rtk_hit));
 			uint8_t *m = (uint8_t *)take(want * 4);
-			if (base == pinned) { h_rays = r; h_rec = rec; h_after = aft; h_hits = hh; h_mask = m; }
+			unsigned long long *st = (unsigned long long *)take(64);
+			if (base == pinned) { h_rays = r; h_rec = rec; h_after = aft; h_hits = hh; h_mask = m; h_status = st; *st = 0ull; }
 			else { d_rays = r; d_rec = rec; d_after = aft; d_hits = hh; d_mask = m; }
 		};
 		carve(pinned);
@@ -338,7 +343,7 @@ bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n,
 	memcpy(c.h_rays, rays, n * sizeof(rtk_ray));
 	// Small pieces skip the copy engines altogether: the pinned staging memory is visible to the device, so the kernels
 	// read the rays from it and write hits and mask into it over PCIe themselves -- two launches and one synchronisation
-	// instead of those plus four copies (rtk_trace_ray: 74 us -> 50 us, profiles/r02_single_ray_latency.log).
+	// instead of those plus four copies (rtk_trace_ray: 74 us -> 50 us; 34 us with the status word and the ticket below, profiles/r02_single_ray_latency.log).
 	const bool zero_copy = n <= ZERO_COPY_RAYS && !with_after;
 	const rtk_ray *d_rays = zero_copy ? c.h_rays : c.d_rays;
 	if (!zero_copy && hipMemcpyAsync(c.d_rays, c.h_rays, n * sizeof(rtk_ray), hipMemcpyHostToDevice, c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays: H2D copy failed"); return false; }
@@ -350,8 +355,12 @@ bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n,
 		f.d_after = c.d_after;
 	}
 	if (rtk_launch_trace(ds, d_rays, n, c.d_rec, nullptr, nullptr, c.stream, false, nullptr, with_after ? &f : nullptr) != RTK_AMD_OK) return false;
+	c.status_mirrored = false;
 	if (zero_copy) {
-		if (rtk_launch_expand(ds, c.d_rec, n, want_hits ? c.h_hits : nullptr, c.h_mask, c.stream) != RTK_AMD_OK) return false;
+		c.ticket_in_flight = 0;
+		if (n <= 256) { c.ticket = c.ticket == 0xffffffffu ? 1u : c.ticket + 1u; c.ticket_in_flight = c.ticket; }
+		if (rtk_launch_expand(ds, c.d_rec, n, want_hits ? c.h_hits : nullptr, c.h_mask, c.stream, c.h_status, c.ticket_in_flight) != RTK_AMD_OK) return false;
+		c.status_mirrored = true;
 	} else {
 		if (rtk_launch_expand(ds, c.d_rec, n, want_hits ? c.d_hits : nullptr, c.d_mask, c.stream) != RTK_AMD_OK) return false;
 		bool ok = hipMemcpyAsync(c.h_mask, c.d_mask, n, hipMemcpyDeviceToHost, c.stream) == hipSuccess;
@@ -364,7 +373,22 @@ bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n,
 // Second half: wait for the piece, then hand its results to the caller's arrays. Returns the hits, (size_t)-1 on error.
 size_t finish_piece(rtk_dev_scene *ds, HostCtx &c, size_t n, rtk_hit *hits, uint8_t *hit_mask)
 {
-	if (rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return (size_t)-1;      // synchronises the stream
+	if (c.status_mirrored) {
+		// the error word came down with the results: one synchronisation, no transfer (the slow path below reports and resets it)
+		bool arrived = false;
+		if (c.ticket_in_flight) {
+			// a lone workgroup signs off with the ticket after its results (release store at system scope): poll for it -- a wait
+			// on the stream costs the runtime's wake-up latency on top -- and fall back to the stream after ~2 ms without it
+			const volatile unsigned long long *w = c.h_status;
+			const auto t0 = std::chrono::steady_clock::now();
+			for (uint32_t spin = 0;; spin++) {
+				if ((uint32_t)(__atomic_load_n(w, __ATOMIC_ACQUIRE) >> 32) == c.ticket_in_flight) { arrived = true; break; }
+				if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+			}
+		}
+		if (!arrived && hipStreamSynchronize(c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays: %s", hipGetErrorString(hipGetLastError())); return (size_t)-1; }
+		if ((*c.h_status & 0xffffffffull) != 0ull && rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return (size_t)-1;
+	} else if (rtk_trace_status(ds, c.stream) != RTK_AMD_OK) return (size_t)-1;      // synchronises the stream
 	size_t count = 0;
 	for (size_t i = 0; i < n; i++) {
 		if (c.h_mask[i]) { count++; if (hits) hits[i] = c.h_hits[i]; }           // misses stay untouched (rtk.c:571-576)
