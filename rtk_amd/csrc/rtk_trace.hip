@@ -141,7 +141,7 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32
 #define RTK_IS_LEAF(top_) ((top_) < RTK_REF_RETRY && (int32_t)(top_) < 0)
 
 #ifndef PL_MIN_WAVES
-#define PL_MIN_WAVES 5             // waves per SIMD the register allocator must leave room for (82 VGPRs used; LDS allows five workgroups per CU)
+#define PL_MIN_WAVES 5             // waves per SIMD the register allocator must leave room for (78 VGPRs used; LDS allows five workgroups per CU)
 #endif
 
 template <int MODE /*0 closest, 1 any, 2 collect the k closest candidates*/, bool COUNT, bool FILT /*built-in candidate filters*/, bool QN /*64 B compressed nodes*/>
