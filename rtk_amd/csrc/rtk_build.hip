@@ -1540,6 +1540,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	// compressed nodes beside the exact ones (and, if the collapse had to go through the workspace, the exact ones out of it)
 	if (rtk_quantize_nodes(ds, 0, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
 	if (hipStreamSynchronize(0) != hipSuccess) return fail("sync");   // the workspace is handed back below
+	rtk_quantize_finish(ds);
 
 	ds->view.tris = d_tris;
 	ds->view.vertex_index = d_vertex_index;

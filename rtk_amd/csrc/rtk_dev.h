@@ -35,8 +35,15 @@ struct DevNode {
 	float by[2][4];
 	float bz[2][4];
 	uint32_t child[4];
-	uint32_t pad[4];
+	// Front-to-back order of the four children for each of the eight direction-sign octants (octant o: bit 0 = x negative,
+	// bit 1 = y negative, bit 2 = z negative), written by k_quantize from the child boxes alone (centre of the box along
+	// the octant's diagonal; empty slots last). order[o >> 1], half (o & 1): bits 0-7 = the permutation (position q, nearest
+	// first -> child slot, two bits each), bits 8-13 = for each pair of slots (0,1) (0,2) (0,3) (1,2) (1,3) (2,3) whether the
+	// SECOND comes before the first. The packet kernel orders the children a tile enters by these instead of sorting entry
+	// distances (any order gives the same hits: DESIGN.md 3.2); not part of the content hash, not exported.
+	uint32_t order[4];
 };
+#define RTK_ORDER_PAIR_SHIFT 8
 static_assert(sizeof(DevNode) == 128, "node must be one 128 B line");
 
 // Compressed node for the per-lane kernels, 64 B = half a cache line (two children of one parent share a line):
@@ -68,8 +75,16 @@ struct DevTri {
 };
 static_assert(sizeof(DevTri) == RTK_TRI_STRIDE, "triangle record stride");
 
+// A few words per scene that kernels read and k_quantize writes (device memory).
+struct DevSceneConsts {
+	float bound_abs;           // no plane of any node lies farther than this from the origin on its axis (>= 1: empty slots carry +1 / -1)
+	uint32_t qnode_misfits;    // nodes whose child boxes do not fit the 8-bit grid (non-finite extents): the scene then keeps to its exact nodes
+	uint32_t reserved[2];
+};
+
 // Everything a kernel needs to know about a scene (passed by value).
 struct DevSceneView {
+	const DevSceneConsts *consts;
 	const DevNode *nodes;
 	const DevNodeQ *qnodes;        // same tree, compressed boxes (may be NULL)
 	const DevTri *tris;
@@ -106,6 +121,8 @@ struct rtk_dev_scene {
 	uint32_t stack_entries = 0;
 	uint64_t total_bytes = 0;
 	double build_ms = 0.0;
+	DevSceneConsts consts_readback = {};   // filled by the stream that ran k_quantize; read by rtk_quantize_finish after its synchronisation
+	float bound_abs = 0.0f;
 	// owned device allocations
 	std::vector<void *> allocs;
 	// per-stream launch scratch, created on first use; the mutex covers the list and the enqueue of a launch
@@ -139,7 +156,11 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
 
 // -- compressed node array (rtk_quant.hip): fills ds->view.qnodes from ds->view.nodes on `stream` --
 // src: read the exact nodes from there and store them to ds->view.nodes as well; dst: compressed array the caller allocated
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr);
+// Also writes every node's child order words and the scene constants (DevSceneConsts, allocated here). bound_hint: a bound of
+// |plane| over all nodes the caller already knows (uploads: computed on the host, boxes of a blob need not nest); the root's
+// own planes are always taken in.
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr, float bound_hint = 0.0f);
+void rtk_quantize_finish(rtk_dev_scene *ds);   // after that stream has been synchronised
 
 // -- radix sort shared with the builder (rtk_build.hip) --
 size_t rtk_sort_scratch_words(uint32_t n);

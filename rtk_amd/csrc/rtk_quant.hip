@@ -18,14 +18,53 @@ __device__ __forceinline__ float grid_step(float extent)
 	return s;
 }
 
+// Front-to-back order of the children per direction octant (DevNode::order): by the centre of the child box along the
+// octant's diagonal, empty slots last, ties by slot number.
+__device__ __forceinline__ void child_order(const DevNode &nd, uint32_t order[4])
+{
+	order[0] = order[1] = order[2] = order[3] = 0u;
+	for (uint32_t o = 0; o < 8u; o++) {
+		float key[4];
+		for (int k = 0; k < 4; k++) {
+			const float cx = nd.bx[0][k] + nd.bx[1][k], cy = nd.by[0][k] + nd.by[1][k], cz = nd.bz[0][k] + nd.bz[1][k];
+			float s = ((o & 1u) ? -cx : cx) + ((o & 2u) ? -cy : cy) + ((o & 4u) ? -cz : cz);
+			if (!(s == s)) s = INFINITY;                           // NaN boxes sort behind everything real
+			key[k] = nd.child[k] == RTK_REF_NONE ? INFINITY : s;
+		}
+		// rank of slot k = how many slots come before it
+		uint32_t word = 0u, pair = 0u, bit = 0u;
+		for (int i = 0; i < 4; i++) {
+			uint32_t rank = 0;
+			for (int j = 0; j < 4; j++) if (j != i && (key[j] < key[i] || (key[j] == key[i] && j < i))) rank++;
+			word |= (uint32_t)i << (2u * rank);
+			for (int j = i + 1; j < 4; j++, bit++) if (key[j] < key[i]) pair |= 1u << bit;   // the second of the pair comes first
+		}
+		word |= pair << RTK_ORDER_PAIR_SHIFT;
+		order[o >> 1] |= word << (16u * (o & 1u));
+	}
+}
+
 // copy_to: also store the exact node there (the device build hands its workspace copy over in the same pass)
-__global__ void k_quantize(const DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *copy_to)
+__global__ void k_quantize(DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *copy_to, DevSceneConsts *consts, float bound_hint)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const DevNode nd = nodes[i];
+	DevNode nd = nodes[i];
+	child_order(nd, nd.order);
 	if (copy_to) copy_to[i] = nd;
+	else *reinterpret_cast<uint4 *>(nodes[i].order) = make_uint4(nd.order[0], nd.order[1], nd.order[2], nd.order[3]);
+	if (i == 0u) {
+		// every box of a tree the device builds lies inside the root's (exact unions); an upload passes the bound over all nodes
+		float b = fmaxf(bound_hint, 1.0f);
+		for (int k = 0; k < 4; k++) {
+			if (nd.child[k] == RTK_REF_NONE) continue;
+			const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
+			for (int c = 0; c < 6; c++) b = (fabsf(v[c]) <= 3.0e38f) ? fmaxf(b, fabsf(v[c])) : INFINITY;   // NaN / inf planes: no bound
+		}
+		consts->bound_abs = b;
+	}
 	DevNodeQ q;
+	bool misfit = false;
 	const float *lo[3] = { nd.bx[0], nd.by[0], nd.bz[0] }, *hi[3] = { nd.bx[1], nd.by[1], nd.bz[1] };
 #pragma unroll
 	for (int a = 0; a < 3; a++) {
@@ -53,6 +92,8 @@ __global__ void k_quantize(const DevNode *nodes, uint32_t n, DevNodeQ *out, DevN
 				wh |= (qh & 255u) << (8 * k);
 			}
 			if (fits) break;
+			// (an extent that is not finite in float -- planes beyond +-1.7e38 or inf -- never fits: frexpf(inf) gives a tiny step)
+			if (attempt == 3) misfit = true;
 			s *= 2.0f;
 		}
 		q.org[a] = mn;
@@ -62,23 +103,43 @@ __global__ void k_quantize(const DevNode *nodes, uint32_t n, DevNodeQ *out, DevN
 	}
 	for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
 	out[i] = q;
+	// a compressed box that does not contain its exact box would cull real hits: the host then keeps the scene on its exact nodes
+	if (misfit) atomicAdd(&consts->qnode_misfits, 1u);
 }
 
 } // namespace
 
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst)
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst, float bound_hint)
 {
 	const uint32_t n = ds->view.num_nodes;
 	void *p = dst;
+	if (!ds->view.consts) {
+		void *c = nullptr;
+		RTK_HIP_CHECK(hipMalloc(&c, sizeof(DevSceneConsts)), RTK_AMD_ERR_OOM);
+		ds->allocs.push_back(c);
+		ds->view.consts = (const DevSceneConsts *)c;
+	}
+	DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
+	RTK_HIP_CHECK(hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), stream), RTK_AMD_ERR_HIP);   // (bound_abs 0 = no nodes; kernels read it as max(bound, 1))
 	if (!p) {
 		RTK_HIP_CHECK(hipMalloc(&p, (size_t)(n ? n : 1) * sizeof(DevNodeQ)), RTK_AMD_ERR_OOM);
 		ds->allocs.push_back(p);
 		ds->total_bytes += (size_t)n * sizeof(DevNodeQ);
 	}
 	// src: the nodes still sit in a workspace; ds->view.nodes (allocated, not yet filled) receives them in the same pass
-	if (n) hipLaunchKernelGGL(k_quantize, dim3((n + 255u) / 256u), dim3(256), 0, stream, src ? src : ds->view.nodes, n, (DevNodeQ *)p,
-		src ? const_cast<DevNode *>(ds->view.nodes) : (DevNode *)nullptr);
+	if (n) hipLaunchKernelGGL(k_quantize, dim3((n + 255u) / 256u), dim3(256), 0, stream, const_cast<DevNode *>(src ? src : ds->view.nodes), n, (DevNodeQ *)p,
+		src ? const_cast<DevNode *>(ds->view.nodes) : (DevNode *)nullptr, consts, bound_hint);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	ds->view.qnodes = (const DevNodeQ *)p;
+	// the misfit count comes back with the caller's own synchronisation of `stream` (rtk_quantize_finish)
+	RTK_HIP_CHECK(hipMemcpyAsync(&ds->consts_readback, consts, sizeof(DevSceneConsts), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
+}
+
+// After the stream of rtk_quantize_nodes has been synchronised: a scene with a node that does not fit the 8-bit grid
+// (non-finite child extents) is traced with its exact nodes only.
+void rtk_quantize_finish(rtk_dev_scene *ds)
+{
+	ds->bound_abs = ds->consts_readback.bound_abs;
+	if (ds->consts_readback.qnode_misfits != 0u) ds->view.qnodes = nullptr;
 }

@@ -41,21 +41,23 @@ __device__ __forceinline__ float asf(int v) { return __int_as_float(v); }
 // 128 B node through the scalar cache. The six plane rows are fetched at byte offsets chosen once
 // per packet from the direction sign bits (near row first), exactly like the reference indexes
 // bounds_x[sign_x] (rtk.c:458-463): no selects afterwards.
-struct PkNode { i32x4 nx, fx, ny, fy, nz, fz, ch; };
+// `ord`: the word of DevNode::order that holds the front-to-back child order for this packet's direction octant.
+struct PkNode { i32x4 nx, fx, ny, fy, nz, fz, ch; int ord; };
 __device__ __forceinline__ void s_load_node(const char *addr, uint32_t onx, uint32_t ofx, uint32_t ony, uint32_t ofy,
-	uint32_t onz, uint32_t ofz, PkNode &n)
+	uint32_t onz, uint32_t ofz, uint32_t oord, PkNode &n)
 {
 	asm volatile(
-		"s_load_dwordx4 %0, %7, %8\n\t"
-		"s_load_dwordx4 %1, %7, %9\n\t"
-		"s_load_dwordx4 %2, %7, %10\n\t"
-		"s_load_dwordx4 %3, %7, %11\n\t"
-		"s_load_dwordx4 %4, %7, %12\n\t"
-		"s_load_dwordx4 %5, %7, %13\n\t"
-		"s_load_dwordx4 %6, %7, 0x60\n\t"
+		"s_load_dwordx4 %0, %8, %9\n\t"
+		"s_load_dwordx4 %1, %8, %10\n\t"
+		"s_load_dwordx4 %2, %8, %11\n\t"
+		"s_load_dwordx4 %3, %8, %12\n\t"
+		"s_load_dwordx4 %4, %8, %13\n\t"
+		"s_load_dwordx4 %5, %8, %14\n\t"
+		"s_load_dwordx4 %6, %8, 0x60\n\t"
+		"s_load_dword %7, %8, %15\n\t"
 		"s_waitcnt lgkmcnt(0)"
-		: "=&s"(n.nx), "=&s"(n.fx), "=&s"(n.ny), "=&s"(n.fy), "=&s"(n.nz), "=&s"(n.fz), "=&s"(n.ch)
-		: "s"(addr), "s"(onx), "s"(ofx), "s"(ony), "s"(ofy), "s"(onz), "s"(ofz)
+		: "=&s"(n.nx), "=&s"(n.fx), "=&s"(n.ny), "=&s"(n.fy), "=&s"(n.nz), "=&s"(n.fz), "=&s"(n.ch), "=&s"(n.ord)
+		: "s"(addr), "s"(onx), "s"(ofx), "s"(ony), "s"(ofy), "s"(onz), "s"(ofz), "s"(oord)
 		: "memory");
 }
 
@@ -93,9 +95,15 @@ __device__ __forceinline__ int sort_key(float f)
 	return b ^ ((b >> 31) & 0x7fffffff);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct PkLane {
-	// ray
-	float ox, oy, oz, rdx, rdy, rdz, tmin, tmax;
+	// ray. The slab test of the fast path is t = plane * (1/d) - c with c = o * (1/d) -+ margin folded in (see pk_slab2): per axis
+	// the pair (1/d, c of the plane row fetched first), then the constants of the rows fetched second, and min_t. Pairs, so that
+	// v_pk_fma_f32 can take both of its per-lane operands from 64-bit registers by half (op_sel) without duplicating any value.
+	f32x2 px, py, pz;      // (1/d, c0) per axis
+	f32x2 q1, q2;          // (c1x, c1y), (c1z, min_t)
+	float tmax;
 	float sox, soy, soz, shx, shy, shz;
 	bool kz0, kz1, sx, sy, sz;
 	// best hit
@@ -162,7 +170,7 @@ __device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, const i32x8 &
 	zz = zz + w * z2;
 	const float t = zz * rcp;
 	const uint32_t prim = (uint32_t)a[3];
-	const bool ok = lanes && !(neg && pos) && t > L.tmin && t < L.tmax;          // rtk.c:354
+	const bool ok = lanes && !(neg && pos) && t > L.q2.y && t < L.tmax;          // rtk.c:354
 	const bool take = ok && (t < L.t || (t == L.t && prim < L.prim));            // rtk.c:371 + canonical ties
 	// selects, not branches: a branch costs three exec-mask regions per triangle on the scalar unit
 	const float nu = u * rcp, nv = v * rcp;
@@ -170,23 +178,52 @@ __device__ __forceinline__ bool pk_triangle(PkLane &L, bool lanes, const i32x8 &
 	return zero;
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ f32x2 mk2(int a, int b) { f32x2 r; r.x = asf(a); r.y = asf(b); return r; }
 
+// rows (two children's planes, scalar registers) * A[sa] - B[sb] for both children in one instruction; A, B: 64-bit per-lane
+// pairs of which op_sel picks the same half for both results. One rounding (it is an fma), which the margin in c accounts for.
+#define PK_FMA(dst_, rows_, A_, sa_, B_, sb_) \
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #sa_ "," #sb_ "] op_sel_hi:[1," #sa_ "," #sb_ "] neg_lo:[0,0,1] neg_hi:[0,0,1]" \
+		: "=v"(dst_) : "s"(rows_), "v"(A_), "v"(B_))
+
+__device__ __forceinline__ float pk_max2(float a, float b) { float r; asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float pk_min2(float a, float b) { float r; asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float pk_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float pk_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // Slab test of children C0 and C0+1 for every lane; node rows in SGPRs (near rows first when the
-// packet's direction signs are uniform). Two children at a time so that the (bound - origin) * rcp
-// of rtk.c:458-463 maps onto v_pk_add_f32 / v_pk_mul_f32. Writes the per-lane entry distance, or
+// packet's direction signs are uniform). Two children at a time. Writes the per-lane entry distance, or
 // NaN where the lane does not enter the child.
+//
+// FAST (every ray of the packet is "tame", see the kernel): plane parameter t = plane * (1/d) - c in ONE v_pk_fma_f32 per
+// row and pair of children (the reference's (plane - o) * (1/d), rtk.c:458-463, is two), where c = o * (1/d) + m for the row
+// that bounds the interval from below and c = o * (1/d) - m for the other, m = 2^-21 * |1/d| * (|o| + B), B = the largest
+// |plane| of the scene. The two forms differ by rounding only: |fl(fl(p - o) * r) - (p - o) r| <= 2.01 u |p - o||r| and
+// |fma(p, r, -fl(o r)) - (p - o) r| <= u |o r| + 1.01 u |p - o||r| (u = 2^-24), together below 5 u (|o| + B)|r| < m with the
+// rounding of c itself. So every near parameter here is <= the reference's and every far parameter >=: each child the exact
+// test admits is admitted (as with the compressed nodes of the per-lane kernels, culling only gets more conservative and the
+// triangles decide the result), at 12 instead of 24 packed instructions per node step.
+// !FAST: the reference's arithmetic verbatim, SSE operand order of min / max, child words looked at.
 template <bool UNIFORM_SIGN, bool FAST, int C0>
 __device__ __forceinline__ void pk_slab2(const PkLane &L, const PkNode &n, bool live, float &pay0, float &pay1)
 {
 	const f32x2 rx0 = mk2(n.nx[C0], n.nx[C0 + 1]), rx1 = mk2(n.fx[C0], n.fx[C0 + 1]);
 	const f32x2 ry0 = mk2(n.ny[C0], n.ny[C0 + 1]), ry1 = mk2(n.fy[C0], n.fy[C0 + 1]);
 	const f32x2 rz0 = mk2(n.nz[C0], n.nz[C0 + 1]), rz1 = mk2(n.fz[C0], n.fz[C0 + 1]);
-	f32x2 nx = (rx0 - L.ox) * L.rdx, fx = (rx1 - L.ox) * L.rdx;
-	f32x2 ny = (ry0 - L.oy) * L.rdy, fy = (ry1 - L.oy) * L.rdy;
-	f32x2 nz = (rz0 - L.oz) * L.rdz, fz = (rz1 - L.oz) * L.rdz;
+	f32x2 nx, fx, ny, fy, nz, fz;
+	const float tmin = L.q2.y;
+	if (FAST) {
+		PK_FMA(nx, rx0, L.px, 0, L.px, 1); PK_FMA(fx, rx1, L.px, 0, L.q1, 0);
+		PK_FMA(ny, ry0, L.py, 0, L.py, 1); PK_FMA(fy, ry1, L.py, 0, L.q1, 1);
+		PK_FMA(nz, rz0, L.pz, 0, L.pz, 1); PK_FMA(fz, rz1, L.pz, 0, L.q2, 0);
+	} else {
+		// the origin back out of its sheared permutation (rtk.c:232-243 the other way round), then rtk.c:458-463
+		const float a_ = L.sox, b_ = L.soy, c_ = L.soz;        // (values first: a conditional between members is a conditional between ADDRESSES, and the whole lane state then lives in scratch)
+		const float ox = L.kz0 ? c_ : (L.kz1 ? b_ : a_), oy = L.kz0 ? a_ : (L.kz1 ? c_ : b_), oz = L.kz0 ? b_ : (L.kz1 ? a_ : c_);
+		nx = (rx0 - ox) * L.px.x; fx = (rx1 - ox) * L.px.x;
+		ny = (ry0 - oy) * L.py.x; fy = (ry1 - oy) * L.py.x;
+		nz = (rz0 - oz) * L.pz.x; fz = (rz1 - oz) * L.pz.x;
+	}
 	if (!UNIFORM_SIGN) {
 		// rows were fetched as (min, max); pick near/far per lane
 		const f32x2 ax = nx, bx = fx, ay = ny, by = fy, az = nz, bz = fz;
@@ -196,11 +233,13 @@ __device__ __forceinline__ void pk_slab2(const PkLane &L, const PkNode &n, bool 
 	}
 	float tn0, tf0, tn1, tf1;
 	if (FAST) {
-		tn0 = fmaxf(fmaxf(fmaxf(nx.x, ny.x), nz.x), L.tmin); tf0 = fminf(fminf(fminf(fx.x, fy.x), fz.x), L.t);
-		tn1 = fmaxf(fmaxf(fmaxf(nx.y, ny.y), nz.y), L.tmin); tf1 = fminf(fminf(fminf(fx.y, fy.y), fz.y), L.t);
+		// (written out: behind fmaxf / fminf hipcc first quiets every operand that comes out of an asm statement -- a v_max_f32 x, x
+		// each, twelve per pair of children; no NaN can arise for tame rays, and v_max / v_min quiet their operands anyway)
+		tn0 = pk_max3(pk_max2(nx.x, ny.x), nz.x, tmin); tf0 = pk_min3(pk_min2(fx.x, fy.x), fz.x, L.t);
+		tn1 = pk_max3(pk_max2(nx.y, ny.y), nz.y, tmin); tf1 = pk_min3(pk_min2(fx.y, fy.y), fz.y, L.t);
 	} else {
-		tn0 = sse_max(sse_max(nx.x, ny.x), sse_max(nz.x, L.tmin)); tf0 = sse_min(sse_min(fx.x, fy.x), sse_min(fz.x, L.t));   // rtk.c:464-465
-		tn1 = sse_max(sse_max(nx.y, ny.y), sse_max(nz.y, L.tmin)); tf1 = sse_min(sse_min(fx.y, fy.y), sse_min(fz.y, L.t));
+		tn0 = sse_max(sse_max(nx.x, ny.x), sse_max(nz.x, tmin)); tf0 = sse_min(sse_min(fx.x, fy.x), sse_min(fz.x, L.t));   // rtk.c:464-465
+		tn1 = sse_max(sse_max(nx.y, ny.y), sse_max(nz.y, tmin)); tf1 = sse_min(sse_min(fx.y, fy.y), sse_min(fz.y, L.t));
 	}
 	const float miss = __builtin_nanf("");
 	if (FAST) {
@@ -290,6 +329,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 	float *const spill_t = reinterpret_cast<float *>(p.spill);
 	const char *const nodes = reinterpret_cast<const char *>(p.sc.nodes);
 	const char *const tris = reinterpret_cast<const char *>(p.sc.tris);
+	// largest |plane| of the scene (>= 1: empty slots), for the slab margins; a scene without such a bound (non-finite planes)
+	// or too far out for the margins (see `tame`) sends every ray down the exact path
+	const float bound_abs = fmaxf(p.sc.consts->bound_abs, 1.0f);
+	const bool bound_ok = bound_abs < 0x1p19f;
 
 	// Tiles are dealt through RTK_QUEUES work queues (tile t belongs to queue t % RTK_QUEUES); a wave
 	// starts on the queue of its workgroup (blockIdx % 8 = one XCD under the usual round-robin
@@ -322,13 +365,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 		const unsigned long long ray_index = map_index(alive ? idx : base, p.image_w, p.image_h, p.tile_blocks);
 
 		PkLane L;
+		bool special;
+		float cnx, cfx, cny, cfy, cnz, cfz, rdx_, rdy_, rdz_, tmin_;
 		{
 			// (rays and hit records are streamed past the caches, "nt": read / written once, and the L2 is wanted for the BVH)
 			const f32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.rays + ray_index)));
 			const f32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.rays + ray_index) + 16));
-			L.ox = r0.x; L.oy = r0.y; L.oz = r0.z;
+			const float ox = r0.x, oy = r0.y, oz = r0.z;
 			const float dx = r0.w, dy = r1.x, dz = r1.y;
-			L.tmin = r1.z; L.tmax = r1.w;
+			const float tmin = r1.z;
+			L.tmax = r1.w;
 			// rtk.c:550-566
 			const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
 			const float m = sse_max(sse_max(ax, ay), az);
@@ -338,22 +384,28 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			const float dky = L.kz0 ? dz : (L.kz1 ? dx : dy);
 			const float dkz = L.kz0 ? dx : (L.kz1 ? dy : dz);
 			L.shx = -dkx / dkz; L.shy = -dky / dkz; L.shz = 1.0f / dkz;
-			L.sox = L.kz0 ? L.oy : (L.kz1 ? L.oz : L.ox);
-			L.soy = L.kz0 ? L.oz : (L.kz1 ? L.ox : L.oy);
-			L.soz = L.kz0 ? L.ox : (L.kz1 ? L.oy : L.oz);
-			L.rdx = 1.0f / dx; L.rdy = 1.0f / dy; L.rdz = 1.0f / dz;             // rtk.c:410
+			L.sox = L.kz0 ? oy : (L.kz1 ? oz : ox);
+			L.soy = L.kz0 ? oz : (L.kz1 ? ox : oy);
+			L.soz = L.kz0 ? ox : (L.kz1 ? oy : oz);
+			const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;           // rtk.c:410
 			L.sx = __float_as_uint(dx) >> 31; L.sy = __float_as_uint(dy) >> 31; L.sz = __float_as_uint(dz) >> 31;
 			L.t = L.tmax; L.u = 0.0f; L.v = 0.0f; L.prim = RTK_PRIM_NONE;
+			// "special": the slab products can be NaN, or the ray is so far out or so extreme in direction that the margins of the fast
+			// slab test (pk_slab2) stop being small against the inverted box of an empty child slot (+1 / -1 on every axis), which that
+			// test must miss by arithmetic alone (it does not look at the child word: three scalar instructions per child and node
+			// step). Everybody else (|origin| and the scene's planes < 2^19, 2^-100 < |1/d| < 2^100): an empty slot's near and far
+			// parameter differ by 2 |1/d| against margins of 2^-21 |1/d| (|o| + B) < |1/d| / 2 each, so near > far on every axis.
+			const bool tame = fabsf(ox) < 0x1p19f && fabsf(oy) < 0x1p19f && fabsf(oz) < 0x1p19f &&
+				fabsf(rdx) > 0x1p-100f && fabsf(rdx) < 0x1p100f && fabsf(rdy) > 0x1p-100f && fabsf(rdy) < 0x1p100f &&
+				fabsf(rdz) > 0x1p-100f && fabsf(rdz) < 0x1p100f;
+			special = !(tame && bound_ok && tmin == tmin && L.tmax == L.tmax);
+			// the fast slab test's constants: c = o * (1/d), the margin added for the row that bounds from below, subtracted for the other
+			const float cx = ox * rdx, cy = oy * rdy, cz = oz * rdz;
+			const float mx = 0x1p-21f * (fabsf(rdx) * (fabsf(ox) + bound_abs)), my = 0x1p-21f * (fabsf(rdy) * (fabsf(oy) + bound_abs)),
+				mz = 0x1p-21f * (fabsf(rdz) * (fabsf(oz) + bound_abs));
+			cnx = cx + mx; cfx = cx - mx; cny = cy + my; cfy = cy - my; cnz = cz + mz; cfz = cz - mz;
+			rdx_ = rdx; rdy_ = rdy; rdz_ = rdz; tmin_ = tmin;
 		}
-		// "special": the slab products can be NaN, or -- new -- the ray is so far out or so extreme in direction that the
-		// inverted box of an empty child slot (+1 / -1 on every axis) could round to a non-empty interval. Everybody else
-		// (|origin| < 2^23, 2^-100 < |1/d| < 2^100) misses an empty slot by arithmetic alone: (1-o)*rd and (-1-o)*rd
-		// differ by 2*rd >= 2^-22 of their size, so near > far on every axis, and the FAST slab test below does not look
-		// at the child word at all (three scalar instructions per child and node step on a scalar unit that is 75 % busy).
-		const bool tame = fabsf(L.ox) < 0x1p23f && fabsf(L.oy) < 0x1p23f && fabsf(L.oz) < 0x1p23f &&
-			fabsf(L.rdx) > 0x1p-100f && fabsf(L.rdx) < 0x1p100f && fabsf(L.rdy) > 0x1p-100f && fabsf(L.rdy) < 0x1p100f &&
-			fabsf(L.rdz) > 0x1p-100f && fabsf(L.rdz) < 0x1p100f;
-		const bool special = !(tame && L.tmin == L.tmin && L.tmax == L.tmax);
 		// wave-uniform facts about the packet
 		const unsigned long long m_alive = __builtin_amdgcn_ballot_w64(alive);
 		const bool wave_fast = __builtin_amdgcn_ballot_w64(alive && special) == 0ull;
@@ -364,6 +416,21 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 		const uint32_t onx = usx ? 16u : 0u, ofx = 16u - onx;
 		const uint32_t ony = 32u + (usy ? 16u : 0u), ofy = 80u - ony;
 		const uint32_t onz = 64u + (usz ? 16u : 0u), ofz = 144u - onz;
+		{
+			// the row fetched first is this lane's near row, unless the signs differ inside the packet (rows come as (min, max)
+			// then) and this lane's direction is negative on the axis
+			const bool fx_ = !sign_uniform && L.sx, fy_ = !sign_uniform && L.sy, fz_ = !sign_uniform && L.sz;
+			L.px = (f32x2){ rdx_, fx_ ? cfx : cnx };
+			L.py = (f32x2){ rdy_, fy_ ? cfy : cny };
+			L.pz = (f32x2){ rdz_, fz_ ? cfz : cnz };
+			L.q1 = (f32x2){ fx_ ? cnx : cfx, fy_ ? cny : cfy };
+			L.q2 = (f32x2){ fz_ ? cnz : cfz, tmin_ };
+		}
+		// child order: the node's front-to-back order for the packet's direction octant (the first ray's, if they differ: any
+		// order gives the same hits). Word octant >> 1 of DevNode::order, half octant & 1.
+		const uint32_t lead0 = (uint32_t)__builtin_ctzll(m_alive | (1ull << 63));
+		const uint32_t octant = (uint32_t)((bsx >> lead0) & 1ull) | ((uint32_t)((bsy >> lead0) & 1ull) << 1) | ((uint32_t)((bsz >> lead0) & 1ull) << 2);
+		const uint32_t oord = 0x70u + 4u * (octant >> 1), oshift = 16u * (octant & 1u);
 		const unsigned long long bk0 = __builtin_amdgcn_ballot_w64(alive && L.kz0), bk1 = __builtin_amdgcn_ballot_w64(alive && L.kz1);
 		const bool kz_uniform = (bk0 == 0ull || bk0 == m_alive) && (bk1 == 0ull || bk1 == m_alive);
 		const uint32_t kzmode = !kz_uniform ? 3u : (bk0 != 0ull ? 0u : (bk1 != 0ull ? 1u : 2u));
@@ -384,7 +451,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 				// ---------------------------------------------------- node (wave-uniform)
 				const bool live = __builtin_amdgcn_inverse_ballot_w64(live_m);
 				PkNode nd;
-				s_load_node(nodes + (size_t)top * 128u, onx, ofx, ony, ofy, onz, ofz, nd);
+				s_load_node(nodes + (size_t)top * 128u, onx, ofx, ony, ofy, onz, ofz, oord, nd);
 				if (COUNT && live) c_nodes++;
 				if (COUNT && lane == 0) atomicAdd(p.counter + 7, 1ull);
 				// per lane: entry distance of each child, NaN = this lane does not enter it
@@ -406,7 +473,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 				asm("s_cmp_lg_u64 %4, 0\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_lg_u64 %3, 0\n\ts_addc_u32 %0, %0, %0\n\t"
 					"s_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, %0\n\ts_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0"
 					: "=&s"(any_mask) : "s"(m0), "s"(m1), "s"(m2), "s"(m3) : "scc");
-				const bool a0 = (any_mask & 1u) != 0u, a1 = (any_mask & 2u) != 0u, a2 = (any_mask & 4u) != 0u, a3 = (any_mask & 8u) != 0u;
+				const bool a0 = (any_mask & 1u) != 0u, a1 = (any_mask & 2u) != 0u, a2 = (any_mask & 4u) != 0u;
 				const uint32_t n_any = (uint32_t)__builtin_popcount(any_mask);
 				uint32_t ref[4] = { (uint32_t)nd.ch[0], (uint32_t)nd.ch[1], (uint32_t)nd.ch[2], (uint32_t)nd.ch[3] };
 				if (n_any == 0u) {
@@ -416,53 +483,46 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 					live_m = m0 | m1 | m2 | m3;
 					top = a0 ? ref[0] : (a1 ? ref[1] : (a2 ? ref[2] : ref[3]));
 				} else if (n_any == 2u) {
-					// two children: pick them out (wave-uniform slot numbers), one comparison, one push
-					// six possible pairs, one scalar branch each: plain register moves instead of selects of vector registers by
+					// two children: pick them out (wave-uniform slot numbers) and take the node's own front-to-back order for this
+					// packet's octant -- one bit test -- instead of comparing entry distances (two v_readlane, their keys, a compare).
+					// Six possible pairs, one scalar branch each: plain register moves instead of selects of vector registers by
 					// scalar slot numbers (each such select is a compare, a 64-bit mask and a v_cndmask)
+					const uint32_t ow = (uint32_t)nd.ord >> oshift;
 					float p0, p1;
 					uint32_t r0, r1;
+					bool swap;
+#define PK_PAIR(i_, j_, bit_) p0 = pay[i_]; p1 = pay[j_]; r0 = ref[i_]; r1 = ref[j_]; swap = (ow & (1u << (RTK_ORDER_PAIR_SHIFT + bit_))) != 0u
 					switch (any_mask) {
-					case 3u: p0 = pay[0]; p1 = pay[1]; r0 = ref[0]; r1 = ref[1]; break;
-					case 5u: p0 = pay[0]; p1 = pay[2]; r0 = ref[0]; r1 = ref[2]; break;
-					case 9u: p0 = pay[0]; p1 = pay[3]; r0 = ref[0]; r1 = ref[3]; break;
-					case 6u: p0 = pay[1]; p1 = pay[2]; r0 = ref[1]; r1 = ref[2]; break;
-					case 10u: p0 = pay[1]; p1 = pay[3]; r0 = ref[1]; r1 = ref[3]; break;
-					default: p0 = pay[2]; p1 = pay[3]; r0 = ref[2]; r1 = ref[3]; break;
+					case 3u: PK_PAIR(0, 1, 0); break;
+					case 5u: PK_PAIR(0, 2, 1); break;
+					case 9u: PK_PAIR(0, 3, 2); break;
+					case 6u: PK_PAIR(1, 2, 3); break;
+					case 10u: PK_PAIR(1, 3, 4); break;
+					default: PK_PAIR(2, 3, 5); break;
 					}
-					const int lead = __builtin_ctzll(live_m);          // (never empty here)
-					const int k0 = __builtin_amdgcn_readlane(sort_key(p0), lead), k1 = __builtin_amdgcn_readlane(sort_key(p1), lead);
-					const bool swap = k1 < k0;
+#undef PK_PAIR
 					const float pfar = swap ? p0 : p1, pnear = swap ? p1 : p0;
 					if (sp + 3u <= PK_LDS_STACK) PK_PUSH_LDS(pfar, swap ? r0 : r1);
 					else PK_PUSH(pfar, swap ? r0 : r1);
 					live_m = __builtin_amdgcn_ballot_w64(pnear == pnear);
 					top = swap ? r1 : r0;
 				} else {
-					// order by the entry distance seen by the first live lane; its own misses (NaN) sort behind
-					// its hits, children nobody enters sort last. Keys per lane on the VALU, one readlane each.
-					const int lead = __builtin_ctzll(live_m);          // (never empty here)
-					int key[4];
+					// three or four: walk the node's order for this octant from the far end; every child somebody enters is pushed,
+					// the last one found (the nearest) is entered. Children by scalar slot number: one branch per slot, so that
+					// payload and reference are fixed registers in each arm (no sort, no keys, no v_readlane).
+					const uint32_t ow = (uint32_t)nd.ord >> oshift;
+					const bool lds_ok = sp + 3u <= PK_LDS_STACK;
+					uint32_t left = n_any;
+#define PK_PLACE(c_) { left--; \
+		if (left == 0u) { live_m = __builtin_amdgcn_ballot_w64(pay[c_] == pay[c_]); top = ref[c_]; } \
+		else if (lds_ok) PK_PUSH_LDS(pay[c_], ref[c_]); else PK_PUSH(pay[c_], ref[c_]); }
 #pragma unroll
-					for (int c = 0; c < 4; c++) key[c] = __builtin_amdgcn_readlane(sort_key(pay[c]), lead);
-					key[0] = a0 ? key[0] : 0x7fffffff; key[1] = a1 ? key[1] : 0x7fffffff;
-					key[2] = a2 ? key[2] : 0x7fffffff; key[3] = a3 ? key[3] : 0x7fffffff;
-					// sorting network; keys and references on the scalar side, the per-lane payload follows with
-					// wave-uniform select conditions
-#define PK_CSWAP(a, b) { const bool s_ = key[b] < key[a]; const int ka_ = s_ ? key[b] : key[a], kb_ = s_ ? key[a] : key[b]; \
-	const uint32_t ra_ = s_ ? ref[b] : ref[a], rb_ = s_ ? ref[a] : ref[b]; const float pa_ = s_ ? pay[b] : pay[a], pb_ = s_ ? pay[a] : pay[b]; \
-	key[a] = ka_; key[b] = kb_; ref[a] = ra_; ref[b] = rb_; pay[a] = pa_; pay[b] = pb_; }
-					PK_CSWAP(0, 1) PK_CSWAP(2, 3) PK_CSWAP(0, 2) PK_CSWAP(1, 3) PK_CSWAP(1, 2)
-#undef PK_CSWAP
-					// far children first so that the nearest is popped first (rtk.c:520-535)
-					if (sp + 3u <= PK_LDS_STACK) {
-#pragma unroll
-						for (int i = 3; i >= 1; i--) if (n_any > (uint32_t)i) PK_PUSH_LDS(pay[i], ref[i]);
-					} else {
-#pragma unroll
-						for (int i = 3; i >= 1; i--) if (n_any > (uint32_t)i) PK_PUSH(pay[i], ref[i]);
+					for (int q = 3; q >= 0; q--) {
+						const uint32_t c = (ow >> (2 * q)) & 3u;
+						if (!((any_mask >> c) & 1u)) continue;
+						if (c == 0u) PK_PLACE(0) else if (c == 1u) PK_PLACE(1) else if (c == 2u) PK_PLACE(2) else PK_PLACE(3)
 					}
-					live_m = __builtin_amdgcn_ballot_w64(pay[0] == pay[0]);
-					top = ref[0];
+#undef PK_PLACE
 				}
 			} else {
 				// ---------------------------------------------------- leaf (wave-uniform)

@@ -8,6 +8,8 @@
 // no intersection work happens here.
 #include "rtk_dev.h"
 
+#include <math.h>
+
 #include <string.h>
 
 #include <unordered_map>
@@ -170,7 +172,7 @@ int rtk_blob_to_host_bvh(const rtk_scene *scene, size_t avail, HostBvh *out)
 		memcpy(d.by, n.by, sizeof(d.by));
 		memcpy(d.bz, n.bz, sizeof(d.bz));
 		for (int i = 0; i < 4; i++) {
-			d.pad[i] = 0;
+			d.order[i] = 0;
 			uint32_t ref = RTK_REF_NONE;
 			if (!slot_is_empty(n, i)) {
 				const uint64_t p = n.child[i];
@@ -233,9 +235,22 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h)
 	ds->view.num_nodes = (uint32_t)h.nodes.size();
 	ds->view.num_tris = (uint32_t)h.tris.size();
 	ds->view.num_prims = (uint32_t)prim_slot.size();
-	if (rtk_quantize_nodes(ds, 0) != RTK_AMD_OK || hipStreamSynchronize(0) != hipSuccess) {
+	// boxes of a blob need not nest, so the bound of |plane| the packet kernel's slab margins rest on is taken over every node;
+	// a scene with planes that are not finite (or beyond 1.7e38: their extent would not be) keeps to its exact nodes
+	float bound = 1.0f;
+	bool finite = true;
+	for (const DevNode &nd : h.nodes) {
+		for (int k = 0; k < 4; k++) {
+			if (nd.child[k] == RTK_REF_NONE) continue;
+			const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
+			for (float x : v) { if (!(fabsf(x) <= 1.7e38f)) finite = false; else if (fabsf(x) > bound) bound = fabsf(x); }
+		}
+	}
+	if (!finite) bound = INFINITY;
+	if (rtk_quantize_nodes(ds, 0, nullptr, nullptr, bound) != RTK_AMD_OK || hipStreamSynchronize(0) != hipSuccess) {
 		rtk_dev_scene_free(ds);
 		return nullptr;
 	}
+	rtk_quantize_finish(ds);
 	return ds;
 }

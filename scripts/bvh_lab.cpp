@@ -324,6 +324,163 @@ static void trace(const Ray &r, Cnt &c) {
 	if (hit) c.hits++;
 }
 
+
+// ---- packet simulation: the control flow of rtk_trace_packet_kernel (one 8x8 tile per wave) on the CPU, counting wave-level steps
+// by kind, so that changes of the traversal's SHAPE (entry points shared by a 64x64 block, child order, packet size) can be
+// priced before they are written for the GPU.
+struct PkCnt { uint64_t tiles = 0, steps[5] = {0,0,0,0,0}, pops = 0, pops_culled = 0, tri_steps = 0, pushes = 0, lane_nodes = 0, entries = 0, entry_culled = 0, pre_steps = 0, blocks = 0, entry_list = 0; };
+static int PK_BLOCKS = 0; static int PK_LANES = 64; static int PK_ENTRY_DEPTH = 0; static int PK_ORDER = 0; static int PK_ENTRY_MAX = 1 << 30;
+static std::vector<int> wdepth;   // depth of every wide node (root = 0)
+static std::vector<uint8_t> wperm;  // per node, per octant: child order (4 x 2 bits), by distance of the child box centre along the octant's diagonal
+
+static inline bool slab(const Ray &r, const float *rd, const Box &b, float best, float &tn) {
+	float n = r.tmin, f = best;
+	for (int a = 0; a < 3; a++) { float t0 = (b.mn[a] - r.o[a]) * rd[a], t1 = (b.mx[a] - r.o[a]) * rd[a]; if (t0 > t1) std::swap(t0, t1); n = std::max(n, t0); f = std::min(f, t1); }
+	tn = n; return n <= f;
+}
+
+struct PkEntry { int ref; float tlo; };
+
+// conservative interval slab test of a whole block of rays (same direction signs): lower bound of the entry distance
+static bool block_slab(const std::vector<Ray> &rs, const Box &b, float &tlo) {
+	float lo = 1e30f; bool any = false;
+	for (const Ray &r : rs) { float rd[3] = { 1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2] }; float tn; if (slab(r, rd, b, r.tmax, tn)) { any = true; lo = std::min(lo, tn); } }
+	tlo = lo; return any;
+}
+
+static void block_entries(const std::vector<Ray> &rs, std::vector<PkEntry> &out, PkCnt &c) {
+	// exact union over the block's rays of "enters this node" down to depth PK_ENTRY_DEPTH (what a conservative pre-pass approximates from above)
+	out.clear();
+	struct S { int ref; float tlo; }; std::vector<S> st; st.push_back({ 0, 0.f });
+	while (!st.empty()) {
+		S s = st.back(); st.pop_back();
+		if (s.ref < 0 || wdepth[s.ref] >= PK_ENTRY_DEPTH) { out.push_back({ s.ref, s.tlo }); continue; }
+		c.pre_steps++;
+		const W &w = wide[s.ref];
+		for (int k = 0; k < w.n; k++) { float tlo; if (block_slab(rs, w.b[k], tlo)) st.push_back({ w.ref[k], tlo }); }
+	}
+	std::sort(out.begin(), out.end(), [](const PkEntry &a, const PkEntry &b) { return a.tlo < b.tlo; });
+}
+
+static void trace_packet(const std::vector<Ray> &rs, PkCnt &c, const std::vector<PkEntry> *entries, std::vector<float> *tout) {
+	const int L = (int)rs.size();
+	std::vector<float> best(L), rd(3 * L);
+	std::vector<uint8_t> hit(L, 0);
+	for (int i = 0; i < L; i++) { best[i] = rs[i].tmax; for (int a = 0; a < 3; a++) rd[3 * i + a] = 1.0f / rs[i].d[a]; }
+	struct E { int ref; std::vector<float> te; };
+	std::vector<E> stack;
+	std::vector<uint8_t> live(L, 1);
+	int top = 0; size_t next_entry = 0;
+	bool need_entry = entries != nullptr;
+	c.tiles++;
+	const int oct = (rs[0].d[0] < 0 ? 1 : 0) | (rs[0].d[1] < 0 ? 2 : 0) | (rs[0].d[2] < 0 ? 4 : 0);
+	for (;;) {
+		bool pop = false;
+		if (need_entry) {
+			// take the next entry point of the block that some lane can still reach
+			bool got = false;
+			while (next_entry < entries->size()) {
+				const PkEntry &e = (*entries)[next_entry++]; c.entries++;
+				bool any = false; for (int i = 0; i < L; i++) { live[i] = e.tlo <= best[i]; any |= live[i]; }
+				if (!any) { c.entry_culled++; next_entry = entries->size(); break; }   // sorted by lower bound: nothing behind it can matter either
+				top = e.ref; got = true; break;
+			}
+			if (!got) break;
+			need_entry = false;
+		}
+		if (top >= 0) {
+			const W &w = wide[top];
+			float pay[8][256]; bool any[8]; int n_any = 0;
+			for (int i = 0; i < L; i++) if (live[i]) c.lane_nodes++;
+			for (int k = 0; k < w.n; k++) {
+				any[k] = false;
+				for (int i = 0; i < L; i++) { float tn; if (live[i] && slab(rs[i], &rd[3 * i], w.b[k], best[i], tn)) { pay[k][i] = tn; any[k] = true; } else pay[k][i] = NAN; }
+				n_any += any[k];
+			}
+			c.steps[std::min(n_any, 4)]++;
+			if (n_any == 0) pop = true;
+			else {
+				int lead = 0; while (!live[lead]) lead++;
+				int idx[8], m = 0;
+				for (int k = 0; k < w.n; k++) if (any[k]) idx[m++] = k;
+				if (PK_ORDER == 0) {
+					auto key = [&](int k) { float p = pay[k][lead]; return std::isnan(p) ? 3e38f : p; };
+					std::stable_sort(idx, idx + m, [&](int a, int b) { return key(a) < key(b); });
+				} else {
+					const uint8_t pm = wperm[(size_t)top * 8 + oct]; int pos[4]; for (int q = 0; q < 4; q++) pos[(pm >> (2 * q)) & 3] = q;
+					std::stable_sort(idx, idx + m, [&](int a, int b) { return pos[a] < pos[b]; });
+				}
+				for (int q = m - 1; q >= 1; q--) { E e; e.ref = w.ref[idx[q]]; e.te.assign(pay[idx[q]], pay[idx[q]] + L); stack.push_back(std::move(e)); c.pushes++; }
+				for (int i = 0; i < L; i++) live[i] = !std::isnan(pay[idx[0]][i]);
+				top = w.ref[idx[0]];
+			}
+		} else {
+			const Leaf &l = leaves[~top];
+			for (uint32_t p : l.prims) {
+				c.tri_steps++;
+				for (int i = 0; i < L; i++) if (live[i]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) { best[i] = (float)t; hit[i] = 1; } }
+			}
+			pop = true;
+		}
+		if (pop) {
+			bool found = false;
+			while (!stack.empty()) {
+				E e = std::move(stack.back()); stack.pop_back(); c.pops++;
+				bool any = false; for (int i = 0; i < L; i++) { live[i] = e.te[i] <= best[i]; any |= live[i]; }   // NaN compares false
+				if (any) { top = e.ref; found = true; break; }
+				c.pops_culled++;
+			}
+			if (!found) { if (entries) need_entry = true; else break; }
+		}
+	}
+	if (tout) *tout = best;
+}
+
+static void packet_lab(int W_, int H_, int nblocks) {
+	// depth + per-octant child order of every wide node
+	wdepth.assign(wide.size(), 0);
+	for (size_t i = 0; i < wide.size(); i++) for (int k = 0; k < wide[i].n; k++) if (wide[i].ref[k] >= 0) wdepth[wide[i].ref[k]] = wdepth[i] + 1;
+	wperm.assign(wide.size() * 8, 0);
+	for (size_t i = 0; i < wide.size(); i++) for (int o = 0; o < 8; o++) {
+		const W &w = wide[i]; float key[4] = { 1e30f, 1e30f, 1e30f, 1e30f }; int idx[4] = { 0, 1, 2, 3 };
+		for (int k = 0; k < w.n && k < 4; k++) { float s = 0; for (int a = 0; a < 3; a++) { float cen = PK_ORDER == 2 ? (((o >> a) & 1) ? 2 * w.b[k].mx[a] : 2 * w.b[k].mn[a]) : PK_ORDER == 3 ? (((o >> a) & 1) ? 2 * w.b[k].mn[a] : 2 * w.b[k].mx[a]) : w.b[k].mn[a] + w.b[k].mx[a]; s += ((o >> a) & 1) ? -cen : cen; } key[k] = s; }
+		std::stable_sort(idx, idx + 4, [&](int a, int b) { return key[a] < key[b]; });
+		uint8_t pm = 0; for (int q = 0; q < 4; q++) pm |= (uint8_t)(idx[q] << (2 * q));
+		wperm[i * 8 + o] = pm;
+	}
+	const int tw = PK_LANES == 64 ? 8 : 16, th = PK_LANES == 256 ? 16 : 8;   // 8x8, 16x8, 16x16
+	PkCnt c; double tsum = 0; uint64_t mism = 0;
+	const int bx_n = W_ / 64, by_n = H_ / 64;
+#pragma omp parallel
+	{ PkCnt lc; double ls = 0; uint64_t lm = 0;
+#pragma omp for schedule(dynamic, 1)
+		for (int bi = 0; bi < nblocks; bi++) {
+			const uint64_t h = (uint64_t)(bi + 1) * 0x9E3779B97F4A7C15ull;
+			const int bx = (int)((h >> 20) % bx_n), by = (int)((h >> 40) % by_n);
+			auto mkray = [&](int x, int y) { Ray r; r.o[0] = 0.5f; r.o[1] = 0.5f; r.o[2] = -1.5f; r.d[0] = ((x + 0.5f) / W_ - 0.5f) * 0.7f; r.d[1] = ((y + 0.5f) / H_ - 0.5f) * 0.7f; r.d[2] = 1.0f; r.tmin = 0; r.tmax = 3.402823e38f; return r; };
+			std::vector<PkEntry> ent;
+			if (PK_ENTRY_DEPTH > 0) {
+				std::vector<Ray> all; for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++) all.push_back(mkray(bx * 64 + x, by * 64 + y));
+				block_entries(all, ent, lc); lc.blocks++; lc.entry_list += ent.size();
+			}
+			for (int ty = 0; ty < 64 / th; ty++) for (int tx = 0; tx < 64 / tw; tx++) {
+				std::vector<Ray> rs; for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) rs.push_back(mkray(bx * 64 + tx * tw + x, by * 64 + ty * th + y));
+				std::vector<float> t1; trace_packet(rs, lc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1);
+				for (size_t i = 0; i < rs.size(); i++) { Cnt cc; (void)cc; ls += t1[i] < 1e30f ? t1[i] : 0; }
+				if (PK_ENTRY_DEPTH > 0 || PK_ORDER) { PkCnt dummy; std::vector<float> t0; const int s0 = PK_ORDER; PK_ORDER = 0; trace_packet(rs, dummy, nullptr, &t0); PK_ORDER = s0; for (size_t i = 0; i < rs.size(); i++) lm += t0[i] != t1[i]; }
+			}
+		}
+#pragma omp critical
+		{ c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
+		  c.lane_nodes += lc.lane_nodes; c.entries += lc.entries; c.entry_culled += lc.entry_culled; c.pre_steps += lc.pre_steps; c.blocks += lc.blocks; c.entry_list += lc.entry_list; tsum += ls; mism += lm; }
+	}
+	const double T = (double)c.tiles; const uint64_t st = c.steps[0] + c.steps[1] + c.steps[2] + c.steps[3] + c.steps[4];
+	printf("  packet %d lanes, entry depth %d, order %d: per tile: node steps %.2f (n_any 0/1/2/3/4: %.2f %.2f %.2f %.2f %.2f) tri steps %.2f pushes %.2f pops %.2f (culled %.2f) lane-nodes/ray %.2f",
+		PK_LANES, PK_ENTRY_DEPTH, PK_ORDER, st / T, c.steps[0] / T, c.steps[1] / T, c.steps[2] / T, c.steps[3] / T, c.steps[4] / T, c.tri_steps / T, c.pushes / T, c.pops / T, c.pops_culled / T, (double)c.lane_nodes / (T * PK_LANES));
+	if (PK_ENTRY_DEPTH > 0) printf(" | entries taken %.2f (+%.2f cut) list %.1f per block, pre-pass steps %.1f per block", c.entries / T, c.entry_culled / T, (double)c.entry_list / c.blocks, (double)c.pre_steps / c.blocks);
+	printf(" | t mismatches %llu\n", (unsigned long long)mism);
+}
+
 static std::vector<Ray> load_rays(const char *f) { FILE *fp = fopen(f, "rb"); fseek(fp, 0, SEEK_END); long s = ftell(fp); fseek(fp, 0, SEEK_SET); std::vector<Ray> r(s / 32); if (fread(r.data(), 32, r.size(), fp) != r.size()) abort(); fclose(fp); return r; }
 
 static double tree_sah() {
@@ -349,6 +506,10 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-w")) WIDTH = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-om")) ORDERMODE = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-bins")) SAH_BINS = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-pk")) PK_LANES = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-pe")) PK_ENTRY_DEPTH = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-po")) PK_ORDER = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-pb")) PK_BLOCKS = atoi(argv[++i]);
 	}
 	{ FILE *fp = fopen(trisf, "rb"); fseek(fp, 0, SEEK_END); long s = ftell(fp); fseek(fp, 0, SEEK_SET); tris.resize(s / 4); if (fread(tris.data(), 4, tris.size(), fp) != tris.size()) abort(); fclose(fp); N = tris.size() / 9; }
 	morton_sort();
@@ -375,5 +536,6 @@ int main(int argc, char **argv) {
 		double n = (double)rays.size();
 		printf("  %-14s nodes %.2f leaves %.2f tris %.2f hit %.4f\n", rf, c.nodes / n, c.leaves / n, c.tris / n, c.hits / n);
 	}
+	if (PK_BLOCKS) packet_lab(4096, 4096, PK_BLOCKS);
 	return 0;
 }
