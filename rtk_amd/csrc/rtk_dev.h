@@ -110,6 +110,8 @@ struct LaunchScratch {
 	size_t spill_lanes = 0;
 	void *d_sort = nullptr;                     // ray reordering scratch (RTK_TRACE_SORT_RAYS), grown on demand
 	size_t sort_capacity = 0;                   // rays
+	uint32_t *d_leftover = nullptr;             // tiles the assembly packet kernel hands to the C++ one, grown on demand
+	size_t leftover_capacity = 0;               // tiles
 };
 
 struct rtk_dev_scene {
@@ -121,6 +123,7 @@ struct rtk_dev_scene {
 	uint32_t stack_entries = 0;
 	uint64_t total_bytes = 0;
 	double build_ms = 0.0;
+	double big_leaf_fraction = 0.0;        // leaves of more than three triangles (uploads; device builds make ~none): the assembly packet kernel hands those tiles back
 	DevSceneConsts consts_readback = {};   // filled by the stream that ran k_quantize; read by rtk_quantize_finish after its synchronisation
 	float bound_abs = 0.0f;
 	// owned device allocations

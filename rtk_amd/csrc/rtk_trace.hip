@@ -796,6 +796,7 @@ void rtk_scratch_free(LaunchScratch *s)
 	if (s->d_counter) (void)hipFree(s->d_counter);
 	if (s->d_spill) (void)hipFree(s->d_spill);
 	if (s->d_sort) (void)hipFree(s->d_sort);
+	if (s->d_leftover) (void)hipFree(s->d_leftover);
 	delete s;
 }
 
@@ -865,6 +866,13 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	const bool qn = ds->view.qnodes != nullptr && qnodes_default != 0 && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_EXACT_NODES));
 	const int variant = packet ? (counted ? VARIANT_PACKET_COUNTED : VARIANT_PACKET) : collect ? VARIANT_COLLECT + (qn ? 1 : 0)
 		: ((any_hit ? 1 : 0) | (counted ? 2 : 0) | (filtered ? 4 : 0) | (qn ? 8 : 0));
+	// ... and of those, the hand-written kernel (rtk_packet_hot.S) takes every tile it can and hands the rest to the C++ kernel:
+	// whole 64x64-pixel blocks, at least two per row, a scene whose planes bound the slab margins and whose leaves are small
+	static const int asm_default = getenv("RTK_AMD_PACKET_ASM") ? atoi(getenv("RTK_AMD_PACKET_ASM")) : 1;
+	int hot_blocks_per_cu = 0;
+	const bool hot = packet && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
+		ds->bound_abs < 0x1p19f && ds->big_leaf_fraction <= 0.02 && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&
+		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu);
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
 
@@ -932,7 +940,30 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 
 	// queue heads and visit counters start from zero; a one-block static launch uses neither
 	if (p.dynamic || packet || counted) RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
-	if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
+	if (hot) {
+		const size_t tiles = n >> 6;
+		if (sc->leftover_capacity < tiles) {
+			if (sc->d_leftover) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_leftover); }
+			sc->d_leftover = nullptr;
+			sc->leftover_capacity = 0;
+			RTK_HIP_CHECK(hipMalloc(&sc->d_leftover, tiles * sizeof(uint32_t)), RTK_AMD_ERR_OOM);
+			sc->leftover_capacity = tiles;
+		}
+		PkHotParams hp = {};
+		hp.nodes = p.sc.nodes; hp.tris = p.sc.tris; hp.rays = p.rays; hp.hits = p.hits; hp.counter = p.counter; hp.leftover = sc->d_leftover;
+		hp.num_blocks = (uint32_t)(tiles >> 6);
+		hp.image_w = p.image_w;
+		hp.blocks_per_row = p.image_w >> 6;
+		hp.bpr_magic = (uint32_t)((0x100000000ull + hp.blocks_per_row - 1u) / hp.blocks_per_row);
+		hp.bound_abs = ds->bound_abs > 1.0f ? ds->bound_abs : 1.0f;
+		size_t hot_blocks = (size_t)ds->num_cus * (size_t)hot_blocks_per_cu;
+		if (hot_blocks > blocks_needed) hot_blocks = blocks_needed;
+		const int rc = rtk_packet_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream);
+		if (rc != RTK_AMD_OK) return rc;
+		// the tiles it handed back (mixed signs or axes, untame rays, a big leaf, a deep stack), by the C++ kernel
+		p.tile_list = sc->d_leftover;
+		rtk_packet_launch(p, (unsigned)blocks, stream, false);
+	} else if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
 	else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	if (counted) {

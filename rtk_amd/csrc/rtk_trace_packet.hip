@@ -342,10 +342,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 	const unsigned long long num_tiles = (p.n + 63ull) >> 6;
 	uint32_t queue = blockIdx.x % RTK_QUEUES;
 	uint32_t queues_left = RTK_QUEUES;
+	const unsigned long long list_count = p.tile_list ? p.counter[RTK_LEFTOVER_COUNT_WORD] : 0ull;
 	for (;;) {
 		// ------------------------------------------------------------ next tile of 64 rays
 		unsigned long long tile = 0;
 		bool have = false;
+		if (p.tile_list) {
+			// the tiles the assembly kernel handed back: one list, one head
+			unsigned long long got = 0;
+			if (lane == 0) got = atomicAdd(p.counter + RTK_LEFTOVER_HEAD_WORD, 1ull);
+			got = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+			if (got < list_count) { tile = p.tile_list[got]; have = true; }
+		} else
 		while (queues_left) {
 			unsigned long long got = 0;
 			if (lane == 0) got = atomicAdd(p.counter + RTK_QUEUE_WORD(queue), 1ull);
@@ -590,6 +598,59 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			}
 		}
 	}
+}
+
+// ---- the hand-written kernel: a code object of its own (rtk_packet_hot.S, assembled by the Makefile), carried in this
+// library as a byte array and loaded once per device
+#include "rtk_packet_hot_image.h"
+#include <mutex>
+
+namespace {
+struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; int blocks_per_cu = 0; bool tried = false; };
+std::mutex g_hot_mutex;
+HotModule g_hot[RTK_MAX_DEVICES];
+
+HotModule *hot_module(int device)
+{
+	if (device < 0 || device >= RTK_MAX_DEVICES) return nullptr;
+	std::lock_guard<std::mutex> lock(g_hot_mutex);
+	HotModule &h = g_hot[device];
+	if (!h.tried) {
+		h.tried = true;
+		int cur = -1;
+		if (hipGetDevice(&cur) != hipSuccess || cur != device) return nullptr;      // loaded by a thread that has this device current
+		if (hipModuleLoadData(&h.mod, rtk_packet_hot_image) != hipSuccess || hipModuleGetFunction(&h.fn, h.mod, "rtk_packet_hot") != hipSuccess) {
+			(void)hipGetLastError();
+			h.fn = nullptr;
+		} else {
+			// 64 VGPRs, 96 SGPRs, 16 KB of LDS per workgroup: seven waves per SIMD (the occupancy query reports one more for
+			// kernels at this SGPR count on ROCm 7.2; 800 / (96 + 16) = 7)
+			int nb = 0;
+			if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
+			h.blocks_per_cu = nb > 7 ? 7 : nb;
+		}
+	}
+	return h.fn ? &h : nullptr;
+}
+} // namespace
+
+bool rtk_packet_hot_available(int device, int *blocks_per_cu)
+{
+	HotModule *h = hot_module(device);
+	if (!h) return false;
+	if (blocks_per_cu) *blocks_per_cu = h->blocks_per_cu;
+	return true;
+}
+
+int rtk_packet_hot_launch(int device, const PkHotParams &hp_in, unsigned blocks, hipStream_t stream)
+{
+	HotModule *h = hot_module(device);
+	if (!h) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
+	PkHotParams hp = hp_in;
+	size_t size = sizeof(hp);
+	void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &hp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
+	RTK_HIP_CHECK(hipModuleLaunchKernel(h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
+	return RTK_AMD_OK;
 }
 
 int rtk_packet_occupancy(bool counted)

@@ -4,6 +4,8 @@
 
 #include "rtk_dev.h"
 
+#include <stddef.h>
+
 #ifndef LDS_STACK
 #define LDS_STACK 15           // entries per lane held in LDS: 30 KB per workgroup, so that FIVE workgroups share a CU's 160 KB (with 16
                                // entries = 32 KB only four are placed: -5 % on incoherent rays, -4 % on shadow rays; 14 and 13 spill more)
@@ -37,7 +39,30 @@ struct TraceParams {
 	uint32_t *cand_count;          // MODE 2: how many of them are valid
 	uint32_t cand_k;
 	uint32_t tile_blocks;          // image batches: tiles are numbered block by block (8x8 tiles = 64x64 pixels), not row by row
+	const uint32_t *tile_list;     // packet kernel only: trace the tiles listed here (counter[RTK_LEFTOVER_COUNT_WORD] of them, dealt through
+	                               // counter[RTK_LEFTOVER_HEAD_WORD]) instead of all tiles: what the assembly kernel handed back
 };
+
+// Scratch counter words of the hand-over from the assembly packet kernel (rtk_packet_hot.S) to the C++ one; cleared with the rest
+#define RTK_LEFTOVER_COUNT_WORD 10
+#define RTK_LEFTOVER_HEAD_WORD 11
+
+// Kernel argument of rtk_packet_hot (rtk_packet_hot.S reads these offsets)
+struct PkHotParams {
+	const void *nodes;             //  0
+	const void *tris;              //  8
+	const rtk_ray *rays;           // 16
+	rtk_hit_record *hits;          // 24
+	unsigned long long *counter;   // 32
+	uint32_t *leftover;            // 40  tile numbers handed to the C++ kernel
+	uint32_t num_blocks;           // 48  64x64-pixel blocks of the image
+	uint32_t image_w;              // 52
+	uint32_t blocks_per_row;       // 56
+	uint32_t bpr_magic;            // 60  ceil(2^32 / blocks_per_row): block / blocks_per_row = mul_hi(block, magic)
+	float bound_abs;               // 64  max(largest |plane| of the scene, 1)
+	uint32_t pad;
+};
+static_assert(sizeof(PkHotParams) == 72 && offsetof(PkHotParams, num_blocks) == 48 && offsetof(PkHotParams, bound_abs) == 64, "rtk_packet_hot.S reads this layout");
 
 // DevTri.flags: bit 0 = last triangle of its leaf, bits 8.. = mesh index (for the mesh-mask filter)
 #define RTK_TRI_MESH_SHIFT 8
@@ -78,3 +103,6 @@ __device__ __forceinline__ unsigned long long map_index(unsigned long long i, ui
 // rtk_trace_packet.hip
 int rtk_packet_occupancy(bool counted);
 void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool counted);
+// the hand-written kernel (rtk_packet_hot.S): can this device run it (module loads), and its launch. blocks_per_cu: resident workgroups.
+bool rtk_packet_hot_available(int device, int *blocks_per_cu);
+int rtk_packet_hot_launch(int device, const PkHotParams &hp, unsigned blocks, hipStream_t stream);

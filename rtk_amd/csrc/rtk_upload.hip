@@ -247,6 +247,10 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h)
 		}
 	}
 	if (!finite) bound = INFINITY;
+	// leaves of more than three triangles (the assembly packet kernel hands tiles that meet one to the C++ kernel)
+	size_t leaves = 0, big = 0;
+	for (const DevTri &t : h.tris) if (t.spare != 0u) { leaves++; if (t.spare > 3u) big++; }
+	ds->big_leaf_fraction = leaves ? (double)big / (double)leaves : 0.0;
 	if (rtk_quantize_nodes(ds, 0, nullptr, nullptr, bound) != RTK_AMD_OK || hipStreamSynchronize(0) != hipSuccess) {
 		rtk_dev_scene_free(ds);
 		return nullptr;
