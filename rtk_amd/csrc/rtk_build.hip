@@ -1392,7 +1392,10 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	BuildParams bp;
 	bp.cost_tri = env_float("RTK_AMD_SAH_CT", 1.0f);
 	bp.cost_node = env_float("RTK_AMD_SAH_CN", 0.5f);   // sweeps on MI355X: small leaves win (profiles/r01_sweep_sah2.log)
-	bp.max_leaf = (uint32_t)env_float("RTK_AMD_MAX_LEAF", 8.0f);
+	// leaves of at most three triangles: a leaf of fewer than four is one partial group for the reference's group-of-four rule
+	// (rtk.c:302-336: double-precision edge functions, no redo), which is all the hand-written packet kernel implements; with
+	// cn = 0.5 the SAH rule made 1.008 triangles per leaf at a limit of 8, so nothing of substance changes
+	bp.max_leaf = (uint32_t)env_float("RTK_AMD_MAX_LEAF", 3.0f);
 	if (bp.max_leaf < 1) bp.max_leaf = 1;
 	if (bp.max_leaf > 63) bp.max_leaf = 63;     // 6-bit count in the blob's leaf header (rtk.c:188)
 

@@ -14,6 +14,8 @@
 // order in tri_test() is normative (sign of u,v,w decides hit/miss); see SURVEY.md
 // section 0. Divisions are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 #include "rtk_dev.h"
+
+#include <algorithm>
 #include "rtk_trace_shared.h"
 
 #include <math.h>
@@ -961,8 +963,10 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		const int rc = rtk_packet_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream);
 		if (rc != RTK_AMD_OK) return rc;
 		// the tiles it handed back (mixed signs or axes, untame rays, a big leaf, a deep stack), by the C++ kernel
+		// (a small grid: the list is empty for most batches, and a launch that only finds that out should cost next to nothing)
 		p.tile_list = sc->d_leftover;
-		rtk_packet_launch(p, (unsigned)blocks, stream, false);
+		const size_t left_blocks = std::min<size_t>(blocks, (size_t)ds->num_cus * 2u);
+		rtk_packet_launch(p, (unsigned)left_blocks, stream, false);
 	} else if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
 	else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);

@@ -12,7 +12,7 @@ for d in ["pmc_sq","pmc_sq2"]:
     for f in glob.glob("$R/gpurun_out/$OUT/"+d+"/*/*_counter_collection.csv"):
         agg=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "rtk_trace" in r["Kernel_Name"] and "true" not in r["Kernel_Name"]:
+            if ("rtk_trace" in r["Kernel_Name"] or "rtk_packet_hot" in r["Kernel_Name"]) and "true" not in r["Kernel_Name"]:
                 agg[(r["Kernel_Name"][:40],r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k,v in sorted(agg.items()): print(k, "%.4g"%(sum(v)/len(v)))
 PY
