@@ -43,23 +43,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-KERNEL_SOURCES = ["rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h",
-                  "rtk_amd/csrc/rtk_dev.h", "rtk_amd/csrc/Makefile"]      # (the Makefile: compiler switches change the kernels too)
-CLOCK_GHZ = 2.4                 # MI355X max engine clock (MI355X_MICROARCH.md); the clock held under load is lower
+CLOCK_GHZ = 2.4                 # MI355X max engine clock (MI355X_MICROARCH.md); used only when a summary lacks SQ_BUSY_CYCLES
 SIMDS = 256 * 4
+SHADER_ENGINES = 32             # 8 XCDs x 4: SQ_BUSY_CYCLES is summed over them
 
 
-def kernel_source_sha16():
-    import hashlib
-    h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
-    return h.hexdigest()[:16]
+def kernel_code_sha16(workload):
+    """Identity of the workload's traversal kernel(s): a hash over their gfx950 machine code inside the built library
+    (rtk_amd/kernel_id.py). Comments, host code and other kernels do not change it."""
+    from rtk_amd import api, kernel_id
+    return kernel_id.workload_kernel_sha16(api.LIB_PATH, workload)
 
 
 def load_pmc_summary(workload):
     """Newest committed rocprofv3 PMC summary of this workload (profiles/rNN_<workload>_lbvh_pmc.json), and whether it
-    was measured on the traversal kernels as they are now (scripts/summarize_profile.py records their source hash)."""
+    was measured on the traversal kernels as they are now (scripts/summarize_profile.py records the hash of their code)."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_lbvh_pmc.json" % workload)), reverse=True):
         try:
             pj = json.load(open(f))
@@ -67,7 +65,8 @@ def load_pmc_summary(workload):
             continue
         if "hbm_traffic_bytes_per_launch" not in pj:
             continue
-        return pj, os.path.relpath(f, ROOT), pj.get("kernel_source_sha16") == kernel_source_sha16()
+        mine = kernel_code_sha16(workload)
+        return pj, os.path.relpath(f, ROOT), (mine is not None and pj.get("kernel_code_sha16") == mine)
     return None, None, False
 
 
@@ -80,12 +79,20 @@ def limiter_from_pmc(pj):
     def m(k):
         return c[k]["mean"] if k in c else None
     out = {}
+    # the clock the kernel actually ran at under the profiler: busy cycles summed over the shader engines / its duration
+    clock = m("SQ_BUSY_CYCLES") / SHADER_ENGINES / ns if (m("SQ_BUSY_CYCLES") and ns) else CLOCK_GHZ
+    out["clock_ghz_measured"] = round(clock, 3)
     if m("SQ_ACTIVE_INST_VALU") and ns:
         # SQ_ACTIVE_INST_* count quad-cycles summed over all SIMDs (MI355X_MICROARCH.md, cycle constants)
-        out["valu_busy"] = round(m("SQ_ACTIVE_INST_VALU") * 4.0 / (SIMDS * ns * CLOCK_GHZ), 3)
+        out["valu_busy"] = round(m("SQ_ACTIVE_INST_VALU") * 4.0 / (SIMDS * ns * clock), 3)
     if m("SQ_INSTS_SALU") and ns:
-        # one scalar ALU per CU, shared by its four SIMDs, one instruction per cycle
-        out["salu_issue"] = round(m("SQ_INSTS_SALU") / (SIMDS / 4.0 * ns * CLOCK_GHZ), 3)
+        # one scalar ALU per CU, shared by its four SIMDs, one instruction per cycle (scalar memory instructions and
+        # branches go through the same issue port)
+        scalar = m("SQ_INSTS_SALU") + (m("SQ_INSTS_SMEM") or 0.0) + (m("SQ_INSTS_BRANCH") or 0.0)
+        out["salu_issue"] = round(scalar / (SIMDS / 4.0 * ns * clock), 3)
+        out["instructions_per_64_rays"] = {k[9:].lower(): round(m(k) * 64.0 / pj["rays_per_launch"], 1) for k in
+                                           ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS")
+                                           if m(k) and pj.get("rays_per_launch")}
     if m("SQ_THREAD_CYCLES_VALU") and m("SQ_ACTIVE_INST_VALU"):
         out["valu_lane_utilisation"] = round(m("SQ_THREAD_CYCLES_VALU") / (64.0 * m("SQ_ACTIVE_INST_VALU")), 3)
     if m("SQ_WAIT_ANY") and m("SQ_WAVE_CYCLES"):
@@ -99,11 +106,74 @@ def f32_ulps(a, b):
     return int(abs(int(np.float32(a).view(np.int32)) - int(np.float32(b).view(np.int32))))
 
 
+def other_workload(kind, steps, warmup, frame=4096):
+    """Compact line for one of the other BASELINE.json configs (config 3: incoherent rays on the 1M-triangle scene; config 5:
+    10M-triangle GPU build + any-hit shadow rays), measured in the same process with the library's defaults: value, kernel
+    time from events on the launch stream, the per-ray algorithmic bytes of the counting build, roofline fraction, and the
+    committed counter summary's traffic if it was taken on these kernels. No CPU leg (the parity tests cover these)."""
+    import torch
+    from rtk_amd import api, synth
+    shadow = kind == "shadow"
+    cfg = synth.CONFIGS[5 if shadow else 3]
+    n = frame * frame
+    t0 = time.time()
+    # (scene and rays are made on the GPU: the same counter-based generator, bit for bit -- tests/test_cabi.py)
+    d_tris = synth.t_triangle_soup(cfg["num_tris"], cfg["spread"], cfg["scene_seed"])
+    torch.cuda.synchronize()
+    ds = api.DeviceScene.build([dict(positions=d_tris)])
+    ds.free()
+    ds = api.DeviceScene.build([dict(positions=d_tris)])          # second build: steady state (the first pays code-object load)
+    build_ms = ds.info()["build_ms"]
+    d_rays = synth.t_rays_shadow(n) if shadow else synth.t_rays_incoherent(n)
+    rays = d_rays
+    opts = api.make_opts(sort_rays=shadow)
+    out_bytes = 1 if shadow else HIT_BYTES
+    d_out = torch.empty(n * out_bytes, dtype=torch.uint8, device="cuda")
+    trace = (lambda: ds.trace_any_device(d_rays, n, d_out, opts)) if shadow else (lambda: ds.trace_device(d_rays, n, d_out, opts))
+    _, ctr = ds.trace_any_counted(rays, opts) if shadow else ds.trace_counted(rays, opts)
+    lane_node_bytes = NODE_BYTES if os.environ.get("RTK_AMD_QNODES", "1") == "0" else 64
+    alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * lane_node_bytes + ctr["triangles"] * TRI_BYTES
+    if shadow:
+        alg_bytes += n * (32 + 8 + 2 * 24 + 8)          # the re-ordering pre-pass inside the step (see main)
+    for _ in range(warmup):
+        trace()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t1 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        trace()
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    res = d_out.cpu().numpy()
+    hit_frac = float(res.astype(bool).mean()) if shadow else float((res.view(np.uint32).reshape(-1, 4)[:, 3] != 0xFFFFFFFF).mean())
+    pj, src, fresh = load_pmc_summary(kind)
+    traffic = float(pj["hbm_traffic_bytes_per_launch"]) if (pj and fresh) else None
+    lim = limiter_from_pmc(pj) if (pj and fresh) else None
+    ds.free()
+    del d_rays, d_out, d_tris
+    torch.cuda.empty_cache()
+    from rtk_amd import api as _api
+    _api.lib().rtk_amd_release_workspace()
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    return {"workload": ("config5: 10M-tri soup, GPU LBVH build + %d any-hit shadow rays (re-ordered by entry cell inside every step)" % n) if shadow
+            else ("config3: 1M-tri soup, %d incoherent rays" % n),
+            "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "kernel_ms": round(k_ms, 4),
+            "hit_fraction": round(hit_frac, 4), "bvh_build_ms_device_resident_mesh": round(build_ms, 3),
+            "algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gb_s": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "triangles": round(ctr["triangles"] / n, 2)},
+            "traffic": traffic, "traffic_source": src if traffic else ("none: %s was measured on other kernel code" % src if pj else None),
+            "limiter": {k: v for k, v in lim.items()} if lim else None,
+            "setup_s": round(time.time() - t0, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="coherent", choices=["coherent", "incoherent", "shadow"])
     ap.add_argument("--bvh", default="device", choices=["device", "oracle-blob", "cpu-sah"],
                     help="device = GPU LBVH build (product path); oracle-blob = upload a blob built by the CPU oracle (debug only)")
@@ -119,6 +189,9 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--node-exit", type=int, default=0)
     ap.add_argument("--frame", type=int, default=4096)
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default run (N=1, coherent): do not append the compact config-3 / config-5 lines (other_workloads)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's main figure (default: 16, a one-GPU box's share)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: gloo + CPU tensors + a stand-in tracer that only fills buffers; exercises the "
                          "multi-rank step loop / gather / timing / JSON plumbing in the CPU tests. Prints no perf claim.")
@@ -380,7 +453,7 @@ def main():
     mrays = total_rays / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    kernel_name = ("rtk_trace_packet_kernel<false>" if packet_kernel else
+    kernel_name = ("rtk_packet_hot (hand-written gfx950 assembly) + rtk_trace_packet_kernel<false> on the tiles it hands back" if packet_kernel else
                    "rtk_trace_kernel<%d, false, false, %s>" % (1 if shadow else 0, "true" if lane_node_bytes == 64 else "false"))
     out = {
         "metric": metric,
@@ -412,7 +485,7 @@ def main():
                                       "INCLUDED: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes, %s; the scene is %.0f MB (the MALL "
                                       "holds 256 MiB), so this is %s" % (traffic_src, info.get("total_device_bytes", 0) / 1e6,
                                       "not pure HBM traffic" if info.get("total_device_bytes", 0) < 256 * 2 ** 20 else "mostly HBM traffic")) if traffic else
-                                     ("none: %s was measured on other kernel sources" % traffic_src if pj else None),
+                                     ("none: %s was measured on other kernel code (kernel_code_sha16 differs)" % traffic_src if pj else None),
                      "unit_of_work": unit,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "kernel": kernel_name if not args.sort_rays else kernel_name + " preceded by the re-ordering pre-pass (rtk_ray_bounds_kernel, "
@@ -452,7 +525,12 @@ def main():
         if oracle_blob is None:
             oracle_blob = pyoracle.build_scene([dict(positions=tris)])
         t_cpu_build = time.time() - t0
-        threads = pyoracle.default_threads()
+        threads = args.cpu_threads if args.cpu_threads > 0 else pyoracle.default_threads()
+        try:
+            all_cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            all_cores = os.cpu_count() or 1
+        all_cores = max(1, min(all_cores, pyoracle.lib().ora_max_threads()))
         # bounded sample: every k-th ray of the same batch (a prefix would be all top-of-frame misses)
         probe_sel = np.arange(0, n, max(1, n >> 17))
         t0 = time.time()
@@ -470,6 +548,12 @@ def main():
         t0 = time.time()
         pyoracle.trace(oracle_blob, rays[probe_sel], threads=1)
         rate1 = len(probe_sel) / max(time.time() - t0, 1e-6)
+        # the same sample on every core this process may use ("all host cores, count stated")
+        rate_all = None
+        if all_cores != threads:
+            t0 = time.time()
+            pyoracle.trace(oracle_blob, sample_rays, threads=all_cores)
+            rate_all = sample / max(time.time() - t0, 1e-6)
 
         def parity(oh, om):
             if shadow:
@@ -497,7 +581,10 @@ def main():
         base = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": "%d rays = every %d-th ray of the same batch, closest-hit on the oracle's SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"
                           % (sample, stride, t_cpu_build, threads, rate1 / 1e6),
-                "host_cpus": os.cpu_count()}
+                "host_cpus": os.cpu_count(),
+                "all_cores": {"value": round(rate_all / 1e6, 3), "cores": all_cores, "unit": "Mrays/s",
+                              "what": "the same sample on every core this process may use (os.sched_getaffinity)"} if rate_all else
+                             {"value": round(sample / dt / 1e6, 3), "cores": threads, "unit": "Mrays/s", "what": "the main figure already uses every core"}}
         # (1) the CPU's own BVH: another valid BVH of the same triangles (near-ties may resolve differently)
         base["parity_vs_gpu_oracle_bvh"] = parity(ohits, omask)
         # (2) the SAME BVH: the oracle traverses the blob exported from the GPU-built scene -> bit-exact
@@ -508,6 +595,18 @@ def main():
         else:
             base["parity_vs_gpu_same_bvh"] = base["parity_vs_gpu_oracle_bvh"]
         out["cpu_baseline"] = base
+    if world == 1 and args.workload == "coherent" and args.bvh == "device" and not args.no_other_workloads and not DRY and W == 4096:
+        # BASELINE.json configs 3 and 5 in the same run, so that their numbers are observed by whoever runs the default
+        # command: compact lines, a few steps each, no CPU leg
+        ds.free()
+        del d_rays, d_outs
+        torch.cuda.empty_cache()
+        out["other_workloads"] = {}
+        for kind in ("incoherent", "shadow"):
+            try:
+                out["other_workloads"][kind] = other_workload(kind, steps=max(3, min(args.steps, 10)), warmup=2)
+            except Exception as e:      # the headline line must not die with an extra
+                out["other_workloads"][kind] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -380,9 +380,12 @@ class DeviceScene:
 
     def trace_any_counted(self, rays, opts=None):
         torch = _torch()
-        rays = np.ascontiguousarray(rays)
-        n = rays.shape[0]
-        d_rays = to_device(rays)
+        if hasattr(rays, "data_ptr"):       # a torch tensor of rays already on the device ([n, 8] float32 or raw bytes)
+            d_rays, n = rays, rays.numel() * rays.element_size() // 32
+        else:
+            rays = np.ascontiguousarray(rays)
+            n = rays.shape[0]
+            d_rays = to_device(rays)
         d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
         ctr = TraceCounters()
         torch.cuda.synchronize()
@@ -393,9 +396,12 @@ class DeviceScene:
 
     def trace_counted(self, rays, opts=None):
         torch = _torch()
-        rays = np.ascontiguousarray(rays)
-        n = rays.shape[0]
-        d_rays = to_device(rays)
+        if hasattr(rays, "data_ptr"):
+            d_rays, n = rays, rays.numel() * rays.element_size() // 32
+        else:
+            rays = np.ascontiguousarray(rays)
+            n = rays.shape[0]
+            d_rays = to_device(rays)
         d_rec = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
         ctr = TraceCounters()
         torch.cuda.synchronize()

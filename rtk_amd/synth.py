@@ -160,3 +160,62 @@ def rays_exotic(n=2048, seed=9, tris=None):
     r["max_t"][k % 47 == 0] = np.float32(-1.0)            # reversed interval
     r["min_t"][k % 53 == 0] = np.float32("nan")
     return r
+
+
+# ---- the same generators on a torch device (bit-identical values: integer arithmetic modulo 2^64, then exactly rounded
+# float32 operations). bench.py uses them for the large batches, where numpy on the host costs tens of seconds.
+def _t_splitmix64(x):
+    import torch
+
+    def lsr(v, k):      # logical shift right of int64
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    c1, c2, c3 = (0x9E3779B97F4A7C15 - (1 << 64)), (0xBF58476D1CE4E5B9 - (1 << 64)), (0x94D049BB133111EB - (1 << 64))
+    z = x + c1
+    z = (z ^ lsr(z, 30)) * c2
+    z = (z ^ lsr(z, 27)) * c3
+    return z ^ lsr(z, 31)
+
+
+def t_u01(seed, first, count, device):
+    import torch
+    k = torch.arange(first, first + count, dtype=torch.int64, device=device)
+    h = _t_splitmix64((int(seed) << 40) + k)
+    return ((h >> 40) & 0xFFFFFF).to(torch.float32) * float(2.0 ** -24)
+
+
+def t_triangle_soup(num_tris, spread, seed=1, device="cuda", chunk=1 << 22):
+    """triangle_soup on a torch device: float32 tensor [3 * num_tris, 3]."""
+    import torch
+    out = torch.empty((num_tris, 3, 3), dtype=torch.float32, device=device)
+    sp = torch.tensor(spread, dtype=torch.float32, device=device)
+    for a in range(0, num_tris, chunk):
+        n = min(chunk, num_tris - a)
+        u = t_u01(seed, a * 12, n * 12, device).reshape(n, 12)
+        off = (u[:, 3:12] - 0.5) * sp
+        out[a:a + n] = u[:, 0:3][:, None, :] + off.reshape(n, 3, 3)
+    return out.reshape(num_tris * 3, 3)
+
+
+def _t_rays(o, d, tmin, tmax):
+    import torch
+    n = o.shape[0]
+    r = torch.empty((n, 8), dtype=torch.float32, device=o.device)
+    r[:, 0:3] = o
+    r[:, 3:6] = d
+    r[:, 6] = tmin
+    r[:, 7] = tmax
+    return r
+
+
+def t_rays_incoherent(n, seed=3, first=0, device="cuda"):
+    import torch
+    u = t_u01(seed, first * 6, n * 6, device).reshape(n, 6)
+    o = u[:, 0:3] * 2.0 - 0.5
+    return _t_rays(o, u[:, 3:6] - o, 0.0, float(RTK_INF))
+
+
+def t_rays_shadow(n, seed=5, first=0, light=(0.5, 2.0, 0.5), device="cuda"):
+    import torch
+    u = t_u01(seed, first * 3, n * 3, device).reshape(n, 3)
+    L = torch.tensor(light, dtype=torch.float32, device=device)
+    return _t_rays(u, L[None, :] - u, float(np.float32(1e-4)), 1.0)

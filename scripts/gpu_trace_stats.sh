@@ -3,7 +3,7 @@ OUT=$1; shift
 mkdir -p gpurun_out/$OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$OUT/trace --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $R/gpurun_out/$OUT/bench.json 2> $R/gpurun_out/$OUT/bench.err; echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$OUT/trace --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-workloads "$@" > $R/gpurun_out/$OUT/bench.json 2> $R/gpurun_out/$OUT/bench.err; echo "trace rc=$?"
 python3 - <<PY
 import csv,glob
 for f in glob.glob("$R/gpurun_out/$OUT/trace/*/*_kernel_stats.csv"):

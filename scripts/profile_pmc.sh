@@ -3,7 +3,7 @@ OUT=$1; CTRS=$2; shift; shift
 mkdir -p gpurun_out/$OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --pmc $CTRS -d $R/gpurun_out/$OUT/pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/$OUT/bench.json 2> $R/gpurun_out/$OUT/bench.err; echo "pmc rc=$?"
+timeout -k 10 300 rocprofv3 --pmc $CTRS -d $R/gpurun_out/$OUT/pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-workloads "$@" > $R/gpurun_out/$OUT/bench.json 2> $R/gpurun_out/$OUT/bench.err; echo "pmc rc=$?"
 python3 - <<PY
 import csv,glob,collections
 for f in glob.glob("$R/gpurun_out/$OUT/pmc/*/*_counter_collection.csv"):

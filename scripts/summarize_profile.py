@@ -23,13 +23,16 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     out = {"kernel": KERNEL, "source": src}
-    # identity of the traversal kernels this was measured on (bench.py drops the traffic figure when they change)
-    import hashlib
+    # identity of the traversal kernels this was measured on: a hash over their machine code in the built library
+    # (rtk_amd/kernel_id.py; bench.py drops the traffic figure when it differs). RTK_PROFILE_WORKLOAD names the workload.
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for f in ("rtk_amd/csrc/rtk_trace.hip", "rtk_amd/csrc/rtk_trace_packet.hip", "rtk_amd/csrc/rtk_trace_shared.h", "rtk_amd/csrc/rtk_dev.h", "rtk_amd/csrc/Makefile"):
-        h.update(open(os.path.join(root, f), "rb").read())
-    out["kernel_source_sha16"] = h.hexdigest()[:16]
+    sys.path.insert(0, root)
+    from rtk_amd import kernel_id
+    wl = os.environ.get("RTK_PROFILE_WORKLOAD")
+    if wl:
+        out["workload"] = wl
+        out["kernel_code_sha16"] = kernel_id.workload_kernel_sha16(os.path.join(root, "rtk_amd", "librtk_amd.so"), wl)
+    out["rays_per_launch"] = int(os.environ.get("RTK_PROFILE_RAYS", str(1 << 24)))
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))

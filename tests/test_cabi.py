@@ -142,3 +142,17 @@ def test_c_shard_range_equals_the_python_rule():
             assert end == n
     L.rtk_amd_shard_range(100, 5, 4, C.byref(f), C.byref(c))      # out-of-range rank: empty
     assert c.value == 0
+
+
+def test_torch_generators_equal_numpy_generators():
+    """bench.py makes its large scenes / batches with the torch versions of the counter-based generators: same bits."""
+    import torch
+    from rtk_amd import synth
+    a = synth.triangle_soup(3000, 0.02, 1)
+    b = synth.t_triangle_soup(3000, 0.02, 1, device="cpu", chunk=1000).numpy()
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    for np_fn, t_fn in ((synth.rays_incoherent, synth.t_rays_incoherent), (synth.rays_shadow, synth.t_rays_shadow)):
+        r = np_fn(2048, first=123)
+        t = t_fn(2048, first=123, device="cpu").numpy()
+        rr = np.concatenate([r["origin"], r["direction"], r["min_t"][:, None], r["max_t"][:, None]], 1)
+        assert (rr.view(np.uint32) == t.view(np.uint32)).all()
