@@ -223,11 +223,17 @@ int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_rays, const 
 /* -- host-pointer convenience (PCIe-inclusive, synchronous) --
  * Closest hits of n rays against a scene blob. hits[i] is written where the ray hit
  * (left untouched on a miss, like rtk_trace_ray); hit_mask[i] (optional) gets 0/1.
- * Returns the number of hits, or (size_t)-1 on error. The device copy of the blob is
- * cached per scene pointer until rtk_free_scene / rtk_amd_forget_scene; every lookup re-checks a
- * fingerprint of the blob, so a different blob placed at the same address is uploaded afresh. A blob in
- * caller-owned memory (rtk_finish_build_to, or loaded from disk) keeps its device copy until
- * rtk_amd_forget_scene is called for it. Each calling thread uses its own stream and staging buffers. */
+ * Returns the number of hits, or (size_t)-1 on error. The device copy of the blob is cached per (scene pointer,
+ * current device) until rtk_free_scene / rtk_amd_forget_scene. Every way this library itself writes a blob to an
+ * address (rtk_finish_build, rtk_finish_build_to with either builder) drops what was cached for that address. A
+ * caller that overwrites a blob in place by its own means MUST call rtk_amd_forget_scene(address) before tracing it
+ * again. As a safety net every lookup re-checks the header, the root node and one 4 KB stripe of the blob (a different
+ * one each time, against hashes of all stripes taken at upload): another scene at the same address is noticed at
+ * once, a small in-place edit within size / 4 KB lookups -- not immediately. A blob in caller-owned memory keeps its
+ * device copy until rtk_amd_forget_scene is called for it. Each calling thread uses its own stream and staging
+ * buffers. rtk_trace_ray / rtk_trace_ray_filter (no error channel): a failure that may pass (out of memory, a stream
+ * error) returns false with rtk_amd_last_error() set; one that every later call would repeat (no usable GPU, a scene
+ * that does not validate) prints the error and abort()s unless RTK_AMD_SOFT_ERRORS is set in the environment. */
 size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask);
 /* Batch form of rtk_trace_ray_filter (rtk.h:130) with a host callback: per ray the closest candidate that
  * `filter` accepts. Every candidate of a ray is offered, in increasing (t, primitive id) order (equal-t ones

@@ -73,9 +73,14 @@ __device__ __forceinline__ float ord2f(uint32_t u)
 }
 
 // IDX: 0 implicit (3i,3i+1,3i+2), 1 u16, 2 u32 (rtk.c:1028-1070). F64: positions are doubles (rtk.c:1098, B20).
-// Compile-time variants: the index and position formats are per mesh, so each launch is one straight-line path
-// (a run-time if/else-if/else form of this kernel faulted in round 1; its cause was never reduced, so nothing
-// is claimed about it -- every arm, RTK_TYPE_DEFAULT indices included, is covered by tests/test_gpu_build.py).
+// Compile-time variants: the index and position formats are per mesh, so each launch is one straight-line path.
+// (A run-time form of this kernel, k_ingest(pos, stride, int pos_type, idx, stride, int idx_type, ...), faulted once in
+// round 1 -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the f64 + u16 mesh of test_edge_scene_indexed_multi_mesh,
+// gpurun_out/pytest_dbg.log. That source was never committed, so the cause cannot be settled from the repository; what the
+// recorded dispatch is consistent with is a type code reaching the kernel that selected the 32-bit read of the 16-bit index
+// buffer: garbage indices times a 24-byte stride leave the legal address range. Nothing run-time is left to get wrong: the
+// host validates both type codes -- positions {DEFAULT, REAL, F32, F64}, indices {DEFAULT, U16, U32}, anything else is an
+// error as in rtk.c:1080-1113 -- and picks the variant from the validated codes; every arm is covered by tests/test_gpu_build.py.)
 // The bounds of the triangle centroids (x2, see k_bounds) are taken in the same pass: one 1024-thread workgroup per CU at
 // most, so the six result words see a few hundred atomics, not tens of thousands.
 #define INGEST_BLOCK 1024
@@ -1262,6 +1267,10 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		MeshPlan &pl = plans[mi];
 		const size_t nt = m->num_triangles;
 		if (nt == 0) continue;
+		if (!m->position_cb && m->position.type != RTK_TYPE_DEFAULT && m->position.type != RTK_TYPE_REAL && m->position.type != RTK_TYPE_F32 &&
+			m->position.type != RTK_TYPE_F64) { rtk_set_error("rtk_dev_scene_build: mesh %zu: bad position type %d", mi, (int)m->position.type); return nullptr; }
+		if (!m->index_cb && m->index.data && m->index.type != RTK_TYPE_DEFAULT && m->index.type != RTK_TYPE_U16 && m->index.type != RTK_TYPE_U32) {
+			rtk_set_error("rtk_dev_scene_build: mesh %zu: bad index type %d", mi, (int)m->index.type); return nullptr; }
 		if (m->position_cb || m->index_cb || n < 2) { pl.on_host_decode = true; continue; }
 		if (!m->position.data) { rtk_set_error("rtk_dev_scene_build: mesh %zu has no positions", mi); return nullptr; }
 		pl.f64 = m->position.type == RTK_TYPE_F64;
@@ -1882,6 +1891,7 @@ extern "C" rtk_scene *rtk_finish_build_to(rtk_build *build, void *buffer, size_t
 		if (!buffer || !rtk_cpu_build_write(build->cpu, buffer, size)) return nullptr;      // too small: the build stays alive (rtk.c:1735)
 		rtk_cpu_build_free(build->cpu);
 		delete build;                                                                        // rtk.c:1771
+		rtk_amd_forget_scene((rtk_scene *)buffer);      // whatever blob lived at this address before has no device copy any more
 		return (rtk_scene *)buffer;
 	}
 	if (!build || !build->scene || !buffer) { rtk_set_error("rtk_finish_build_to: build has not run (or failed)"); return nullptr; }

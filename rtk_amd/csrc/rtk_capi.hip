@@ -3,6 +3,8 @@
 // HIP plumbing. No intersection arithmetic lives here and there is no CPU fallback:
 // every trace call runs the HIP kernels of rtk_trace.hip or fails with an error.
 #include "rtk_dev.h"
+
+#include <algorithm>
 #include "rtk_layout_check.h"
 
 #include <stdarg.h>
@@ -156,70 +158,124 @@ extern "C" int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record
 
 // ---------------------------------------------------------------------------- residency cache
 //
-// Host-pointer calls (rtk_trace_ray[s], the reference's own signatures) find the device copy of a blob
-// through its address. The address alone is not an identity: rtk_finish_build_to writes into caller
-// memory that the caller releases with free(), so a different blob can later live at the same address.
-// Every entry therefore carries a fingerprint of the blob (size, header, root node and samples across
-// the body) that is re-checked on every lookup; a mismatch drops the device copy and uploads again.
+// Host-pointer calls (rtk_trace_ray[s], the reference's own signatures) find the device copy of a blob through its
+// address and the calling thread's current device. The address alone is not an identity: rtk_finish_build_to writes
+// into caller memory that the caller releases with free(), so a different blob can later live at the same address.
+//   * Every way this library itself puts a blob at an address (rtk_finish_build[_to] with either builder, rtk_free_scene)
+//     drops or replaces the entry.
+//   * When a blob is uploaded, EVERY 4 KB stripe of it is hashed (one pass, ~1 ns per 8 bytes). A lookup re-checks the
+//     64-byte header and the root node (a different scene of another size or shape is caught at once) plus ONE stripe, a
+//     different one each time, in rotation: a caller that rewrites a blob in place behind the library's back -- one moved
+//     vertex -- is found out within (size / 4 KB) lookups instead of never, at ~0.2 us per call instead of a re-hash of
+//     up to 100 MB. rtk_amd_forget_scene is the immediate, documented way (include/rtk_amd.h).
 
 namespace {
 
-uint64_t fnv1a(const void *data, size_t n, uint64_t h)
+const size_t STRIPE = 4096;
+
+uint64_t hash_words(const void *data, size_t n, uint64_t h)
 {
 	const unsigned char *p = static_cast<const unsigned char *>(data);
-	for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x9e3779b97f4a7c15ull; h ^= h >> 29; }
+	for (; i < n; i++) { h = (h ^ p[i]) * 0x100000001b3ull; }
 	return h;
 }
 
-uint64_t blob_fingerprint(const rtk_scene *scene)
+uint64_t head_hash(const rtk_scene *scene)
 {
-	const char *b = reinterpret_cast<const char *>(scene);
 	const uint64_t size = scene->size_in_bytes;
-	uint64_t h = fnv1a(scene, sizeof(rtk_scene), 0xcbf29ce484222325ull);
-	if (size < 256 || size > ((uint64_t)1 << 48)) return h;        // not a plausible blob; the loader will refuse it
-	h = fnv1a(b + 128, 128, h);                                       // root node
-	const uint64_t step = size / 61 + 1;
-	for (uint64_t at = 256; at + 64 <= size; at += step) h = fnv1a(b + at, 64, h);
-	return fnv1a(b + size - 64, 64, h);
+	uint64_t h = hash_words(scene, sizeof(rtk_scene), 0xcbf29ce484222325ull);
+	if (size >= 256 && size <= ((uint64_t)1 << 48)) h = hash_words(reinterpret_cast<const char *>(scene) + 128, 128, h);   // root node
+	return h;
 }
 
-struct CacheEntry { rtk_dev_scene *ds; uint64_t fingerprint; };
+struct CacheEntry {
+	rtk_dev_scene *ds = nullptr;
+	uint64_t size = 0, head = 0;
+	std::vector<uint64_t> stripes;     // hash of every STRIPE bytes of the blob as it was uploaded
+	size_t next = 0;                   // the stripe the next lookup re-checks
+};
+struct CacheKey {
+	const rtk_scene *scene; int device;
+	bool operator==(const CacheKey &o) const { return scene == o.scene && device == o.device; }
+};
+struct CacheKeyHash { size_t operator()(const CacheKey &k) const { return std::hash<const void *>()(k.scene) ^ ((size_t)k.device * 0x9e3779b97f4a7c15ull); } };
 std::mutex g_cache_mutex;
-std::unordered_map<const rtk_scene *, CacheEntry> g_cache;
+std::unordered_map<CacheKey, CacheEntry, CacheKeyHash> g_cache;
+thread_local bool t_fatal = false;     // the last resident() of this thread failed for good (invalid scene / no device)
+
+void fill_entry(CacheEntry &e, const rtk_scene *scene, rtk_dev_scene *ds)
+{
+	e.ds = ds;
+	e.size = scene->size_in_bytes;
+	e.head = head_hash(scene);
+	e.next = 0;
+	e.stripes.clear();
+	if (e.size >= 256 && e.size <= ((uint64_t)1 << 48)) {
+		const char *b = reinterpret_cast<const char *>(scene);
+		for (uint64_t at = 0; at < e.size; at += STRIPE) e.stripes.push_back(hash_words(b + at, (size_t)std::min<uint64_t>(STRIPE, e.size - at), at));
+	}
+}
+
+int current_device()
+{
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+	return d;
+}
 
 rtk_dev_scene *resident(const rtk_scene *scene)
 {
-	const uint64_t fp = blob_fingerprint(scene);
+	const CacheKey key = { scene, current_device() };
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	auto it = g_cache.find(scene);
+	auto it = g_cache.find(key);
 	if (it != g_cache.end()) {
-		if (it->second.fingerprint == fp) return it->second.ds;
-		rtk_dev_scene_free(it->second.ds);                            // another blob lives at this address now
+		CacheEntry &e = it->second;
+		bool same = e.size == scene->size_in_bytes && e.head == head_hash(scene);
+		if (same && !e.stripes.empty()) {
+			const size_t k = e.next;
+			e.next = (k + 1) % e.stripes.size();
+			const uint64_t at = (uint64_t)k * STRIPE;
+			same = hash_words(reinterpret_cast<const char *>(scene) + at, (size_t)std::min<uint64_t>(STRIPE, e.size - at), at) == e.stripes[k];
+		}
+		if (same) return e.ds;
+		rtk_dev_scene_free(e.ds);                                     // another blob lives at this address now
 		g_cache.erase(it);
 	}
-	rtk_dev_scene *ds = rtk_dev_scene_upload(scene);
-	if (ds) g_cache[scene] = CacheEntry{ ds, fp };
+	// what kind of failure a NULL is: a blob that does not validate or a machine without a usable GPU will fail the same
+	// way on every call ("fatal" for rtk_trace_ray, which has no error channel); running out of memory may not
+	t_fatal = false;
+	HostBvh h;
+	if (rtk_blob_to_host_bvh(scene, (size_t)scene->size_in_bytes, &h) != RTK_AMD_OK) { t_fatal = true; return nullptr; }
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); t_fatal = true; rtk_set_error("no usable HIP device"); return nullptr; }
+	rtk_dev_scene *ds = rtk_dev_scene_from_host_bvh(h);
+	if (ds) fill_entry(g_cache[key], scene, ds);
 	return ds;
 }
 
 } // namespace
 
+bool rtk_last_failure_is_fatal() { return t_fatal; }
+
 void rtk_cache_adopt(const rtk_scene *scene, rtk_dev_scene *ds)
 {
-	const uint64_t fp = blob_fingerprint(scene);
+	const CacheKey key = { scene, ds ? ds->device : current_device() };
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	auto it = g_cache.find(scene);
-	if (it != g_cache.end()) rtk_dev_scene_free(it->second.ds);
-	g_cache[scene] = CacheEntry{ ds, fp };
+	// nothing that lived at this address before is valid any more, on any device
+	for (auto it = g_cache.begin(); it != g_cache.end();) {
+		if (it->first.scene == scene) { rtk_dev_scene_free(it->second.ds); it = g_cache.erase(it); } else ++it;
+	}
+	fill_entry(g_cache[key], scene, ds);
 }
 
 extern "C" void rtk_amd_forget_scene(const rtk_scene *scene)
 {
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	auto it = g_cache.find(scene);
-	if (it == g_cache.end()) return;
-	rtk_dev_scene_free(it->second.ds);
-	g_cache.erase(it);
+	for (auto it = g_cache.begin(); it != g_cache.end();) {
+		if (it->first.scene == scene) { rtk_dev_scene_free(it->second.ds); it = g_cache.erase(it); } else ++it;
+	}
 }
 
 // ---------------------------------------------------------------------------- host-pointer tracing
@@ -231,6 +287,15 @@ extern "C" void rtk_amd_forget_scene(const rtk_scene *scene)
 namespace {
 
 const size_t ZERO_COPY_RAYS = 2048;            // pieces up to this size are read and written in place by the kernels
+
+// this thread's stream is going away: every cached scene drops the scratch set it made for it
+void drop_stream_everywhere(hipStream_t stream)
+{
+	if (!stream) return;
+	(void)hipStreamSynchronize(stream);
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	for (auto &kv : g_cache) rtk_scene_drop_stream(kv.second.ds, stream);
+}
 
 struct HostCtx {
 	int device = -1;
@@ -271,7 +336,7 @@ struct HostCtx {
 	~HostCtx()
 	{
 		release();
-		if (stream) (void)hipStreamDestroy(stream);
+		if (stream) { drop_stream_everywhere(stream); (void)hipStreamDestroy(stream); }
 	}
 	bool ensure(size_t n)
 	{
@@ -279,7 +344,7 @@ struct HostCtx {
 		if (hipGetDevice(&cur) != hipSuccess) { rtk_set_error("no usable HIP device: %s", hipGetErrorString(hipGetLastError())); return false; }
 		if (cur != device) {                   // the thread moved to another GPU
 			release();
-			if (stream) (void)hipStreamDestroy(stream);
+			if (stream) { drop_stream_everywhere(stream); (void)hipStreamDestroy(stream); }
 			stream = nullptr;
 			device = cur;
 		}
@@ -406,6 +471,7 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 {
 	if (!scene || (!rays && n)) { rtk_set_error("rtk_trace_rays: NULL argument"); return (size_t)-1; }
 	if (n == 0) return 0;
+	t_fatal = false;
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
 	if (n < 2 * PIPE_CHUNK) {
@@ -458,6 +524,7 @@ extern "C" size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *r
 	if (!filter) return rtk_trace_rays(scene, rays, n, hits, hit_mask);
 	if (!scene || (!rays && n)) { rtk_set_error("rtk_trace_rays_filter: NULL argument"); return (size_t)-1; }
 	if (n == 0) return 0;
+	t_fatal = false;
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
 	HostCtx &c = t_ctx;
@@ -532,9 +599,11 @@ extern "C" bool rtk_trace_ray(const rtk_scene *scene, const rtk_ray *ray, rtk_hi
 	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray: NULL argument"); return false; }
 	const size_t r = rtk_trace_rays(scene, ray, 1, &h, &m);
 	if (r == (size_t)-1) {
-		// The signature has no error channel and "miss" would be a wrong answer, not an error: report and stop,
-		// unless the host opted into soft failures (then: false, with rtk_amd_last_error() set).
-		if (getenv("RTK_AMD_SOFT_ERRORS")) return false;
+		// The signature has no error channel. A failure that may pass (out of memory, a stream error) returns false with
+		// rtk_amd_last_error() set; one that every later call would repeat -- no usable GPU, a scene that does not validate --
+		// would turn every ray into a silent "miss", a wrong answer rather than an error: report and stop, unless the host
+		// opted into soft failures (RTK_AMD_SOFT_ERRORS: false + rtk_amd_last_error() there too).
+		if (!rtk_last_failure_is_fatal() || getenv("RTK_AMD_SOFT_ERRORS")) return false;
 		fprintf(stderr, "rtk_trace_ray: %s\n", g_error);
 		abort();
 	}
@@ -552,7 +621,7 @@ extern "C" bool rtk_trace_ray_filter(const rtk_scene *scene, const rtk_ray *ray,
 	rtk_hit h;
 	const size_t r = rtk_trace_rays_filter(scene, ray, 1, &h, &m, filter, filter_user);
 	if (r == (size_t)-1) {
-		if (getenv("RTK_AMD_SOFT_ERRORS")) return false;
+		if (!rtk_last_failure_is_fatal() || getenv("RTK_AMD_SOFT_ERRORS")) return false;      // (see rtk_trace_ray)
 		fprintf(stderr, "rtk_trace_ray_filter: %s\n", g_error);
 		abort();
 	}

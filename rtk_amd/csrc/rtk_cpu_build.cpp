@@ -517,6 +517,8 @@ rtk_cpu_build *rtk_cpu_build_start(const rtk_scene_desc *desc, void *owner, rtk_
 		const rtk_mesh *me = &desc->meshes[m];
 		if (me->num_triangles && !me->position.data && !me->position_cb) { rtk_set_error("rtk_start_build: mesh %zu has no positions", m); delete b; return nullptr; }
 		if (me->index.data && me->index.type != RTK_TYPE_U16 && me->index.type != RTK_TYPE_U32 && me->index.type != RTK_TYPE_DEFAULT) { rtk_set_error("rtk_start_build: bad index type"); delete b; return nullptr; }
+		if (me->position.data && !me->position_cb && me->position.type != RTK_TYPE_DEFAULT && me->position.type != RTK_TYPE_REAL && me->position.type != RTK_TYPE_F32 &&
+			me->position.type != RTK_TYPE_F64) { rtk_set_error("rtk_start_build: bad position type"); delete b; return nullptr; }      // rtk.c:1080-1113 asserts
 		b->mesh_base[m + 1] = b->mesh_base[m] + me->num_triangles;
 	}
 	b->num_triangles = (size_t)b->mesh_base.back();

@@ -178,6 +178,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, r
 	const rtk_dev_filter *filter = nullptr, rtk_hit_record *d_cand = nullptr, uint32_t *d_cand_count = nullptr, uint32_t cand_k = 0);
 int rtk_trace_status(const rtk_dev_scene *ds, hipStream_t stream);
 void rtk_scratch_free(LaunchScratch *s);
+void rtk_scene_drop_stream(rtk_dev_scene *ds, hipStream_t stream);   // the stream is about to be destroyed (and has been synchronised)
 // h_status (host-visible): also receives the stream's launch-error word (see rtk_trace_status), or is left alone if the stream has none.
 // ticket != 0 and n <= 256: the word becomes (ticket << 32 | error) once every result of the launch is visible to the host.
 int rtk_launch_expand(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,

@@ -811,6 +811,15 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (collect && (!d_cand_count || cand_k == 0 || any_hit || counted)) { rtk_set_error("rtk_dev_trace: bad collect arguments"); return RTK_AMD_ERR_BAD_ARG; }
 	if (!ds || (!d_rays && n) || (!collect && (any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
+	{
+		// the scene's memory, its scratch and `stream` must all belong to the device this thread has current: a launch from a
+		// thread on another GPU would read the scene across devices (a fault without peer access)
+		int cur = -1;
+		if (hipGetDevice(&cur) != hipSuccess || cur != ds->device) {
+			rtk_set_error("rtk_dev_trace: the scene lives on device %d, the calling thread's current device is %d", ds->device, cur);
+			return RTK_AMD_ERR_BAD_ARG;
+		}
+	}
 	// the kernel addresses nodes and triangles as SGPR base + 32-bit byte offset
 	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * RTK_TRI_STRIDE > 0xffffff00ull) {
 		rtk_set_error("rtk_dev_trace: scene exceeds 4 GiB of nodes or triangles (%u nodes, %u triangles)", ds->view.num_nodes, ds->view.num_tris);
@@ -992,21 +1001,37 @@ int rtk_trace_status(const rtk_dev_scene *ds_c, hipStream_t stream)
 {
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
 	if (!ds) { rtk_set_error("rtk_dev_trace_status: NULL scene"); return RTK_AMD_ERR_BAD_ARG; }
-	std::lock_guard<std::mutex> lock(ds->scratch_mutex);
-	for (LaunchScratch *s : ds->scratch) {
-		if (s->stream != stream) continue;
-		unsigned long long e = 0;
-		RTK_HIP_CHECK(hipMemcpyAsync(&e, s->d_counter + RTK_ERROR_WORD, sizeof(e), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+	// the error word's address is looked up under the lock; the wait for the stream happens outside it, so that threads
+	// tracing one scene on their own streams do not queue up behind each other's synchronisation
+	unsigned long long *word = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(ds->scratch_mutex);
+		for (LaunchScratch *s : ds->scratch) if (s->stream == stream) { word = s->d_counter + RTK_ERROR_WORD; break; }
+	}
+	if (!word) {
 		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
-		if (e) {
-			(void)hipMemsetAsync(s->d_counter + RTK_ERROR_WORD, 0, sizeof(e), stream);      // reported once
-			rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)");
-			return RTK_AMD_ERR_BAD_SCENE;
-		}
 		return RTK_AMD_OK;
 	}
+	unsigned long long e = 0;
+	RTK_HIP_CHECK(hipMemcpyAsync(&e, word, sizeof(e), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 	RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
+	if (e) {
+		(void)hipMemsetAsync(word, 0, sizeof(e), stream);      // reported once
+		rtk_set_error("rtk_dev_trace: traversal stack overflow (corrupted scene)");
+		return RTK_AMD_ERR_BAD_SCENE;
+	}
 	return RTK_AMD_OK;
+}
+
+// A stream is going away (the host-pointer calls own one per thread): the scratch sets made for it are released, so that
+// threads coming and going do not pile them up and a recycled stream handle never finds an old entry.
+void rtk_scene_drop_stream(rtk_dev_scene *ds, hipStream_t stream)
+{
+	if (!ds) return;
+	std::lock_guard<std::mutex> lock(ds->scratch_mutex);
+	for (size_t i = 0; i < ds->scratch.size();) {
+		if (ds->scratch[i]->stream == stream) { rtk_scratch_free(ds->scratch[i]); ds->scratch.erase(ds->scratch.begin() + (long)i); } else i++;
+	}
 }
 
 int rtk_launch_expand(const rtk_dev_scene *ds_c, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,
@@ -1015,6 +1040,13 @@ int rtk_launch_expand(const rtk_dev_scene *ds_c, const rtk_hit_record *d_records
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
 	if (!ds || (!d_records && n)) { rtk_set_error("rtk_dev_expand_hits: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) return RTK_AMD_OK;
+	{
+		int cur = -1;
+		if (hipGetDevice(&cur) != hipSuccess || cur != ds->device) {
+			rtk_set_error("rtk_dev_expand_hits: the scene lives on device %d, the calling thread's current device is %d", ds->device, cur);
+			return RTK_AMD_ERR_BAD_ARG;
+		}
+	}
 	const unsigned long long *status_word = nullptr;
 	if (h_status) {
 		// the error word of the launches on this stream (rtk_launch_trace has made the scratch set)

@@ -476,3 +476,121 @@ def test_builds_and_traces_from_several_threads_at_once(api, oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors[:6]
+
+
+def test_in_place_edit_of_a_cached_blob_is_found_out(api, oracle):
+    """A blob edited in place behind the library's back (same size, same header, same root: one moved triangle): the
+    residency cache re-checks one 4 KB stripe per lookup in rotation, so the stale device copy lives for at most
+    size / 4 KB lookups; rtk_amd_forget_scene is the immediate way (include/rtk_amd.h)."""
+    L = api.lib()
+    tris = synth.triangle_soup(3000, 0.1, seed=77)
+    blob = oracle.build_scene([dict(positions=tris)])
+    buf = oracle._aligned_bytes(blob.size)
+    buf[:] = blob.data
+    rays = synth.rays_config1(2048)
+    hits, mask = api.trace_rays(buf.ctypes.data, rays)
+    k = int(np.nonzero(mask)[0][0])
+    T = int(hits["triangle_index"][k])
+
+    def move_triangle(dz):
+        moved = 0
+        for v in tris.reshape(-1, 3, 3)[T]:
+            pat = np.asarray(v, np.float32).tobytes()
+            raw = buf.tobytes()
+            at = raw.find(pat)
+            while at >= 0:
+                if at % 16 == 0:
+                    z = np.frombuffer(raw, np.float32, 1, at + 8)[0]
+                    buf[at + 8:at + 12] = np.frombuffer(np.float32(z + dz).tobytes(), np.uint8)
+                    moved += 1
+                at = raw.find(pat, at + 1)
+        return moved
+
+    assert move_triangle(50.0) >= 3
+    stripes = (blob.size + 4095) // 4096
+    seen = None
+    for call in range(stripes + 2):
+        h2, m2 = api.trace_rays(buf.ctypes.data, rays)
+        if not (m2[k] and h2["triangle_index"][k] == T):
+            seen = call
+            break
+    assert seen is not None, "the edit was never noticed in %d lookups" % (stripes + 2)
+    oh, om = oracle.trace(oracle.Blob(buf), rays)
+    assert (m2 == om).all() and (h2["triangle_index"][m2] == oh["triangle_index"][om]).all()
+    # the immediate way: edit back, forget, trace
+    buf[:] = blob.data
+    L.rtk_amd_forget_scene(C.c_void_p(buf.ctypes.data))
+    h3, m3 = api.trace_rays(buf.ctypes.data, rays)
+    assert m3[k] and h3["triangle_index"][k] == T
+    L.rtk_amd_forget_scene(C.c_void_p(buf.ctypes.data))
+
+
+def test_cpu_builder_into_a_reused_buffer_drops_the_old_device_copy(api, oracle):
+    """rtk_finish_build_to with the task-graph CPU builder writes a new blob where an old one was traced from: the old
+    device copy must go (only the device builder's branch re-adopted the scene)."""
+    from rtk_amd.types import MeshSet
+    L = api.lib()
+    rays = synth.rays_config1(1024)
+    buf = oracle._aligned_bytes(8 << 20)
+    try:
+        for seed in (51, 52):
+            L.rtk_amd_set_builder(1)
+            tris = synth.triangle_soup(2000, 0.1, seed=seed)
+            ms = MeshSet([dict(positions=tris)])
+            b = L.rtk_start_build(C.byref(ms.desc), None)
+            assert b, api.last_error()
+            size = L.rtk_get_build_size(b)
+            assert 0 < size <= buf.size
+            s = L.rtk_finish_build_to(b, buf.ctypes.data, buf.size)
+            assert s == buf.ctypes.data
+            hits, mask = api.trace_rays(s, rays)
+            oh, om = oracle.trace(oracle.Blob(buf[:size]), rays)
+            assert (mask == om).all() and (hits["triangle_index"][mask] == oh["triangle_index"][om]).all()
+    finally:
+        L.rtk_amd_set_builder(0)
+        L.rtk_amd_forget_scene(C.c_void_p(buf.ctypes.data))
+
+
+def test_bad_type_codes_are_refused(api):
+    """rtk.c:1080-1113 asserts on an unknown position type; here both builders refuse the mesh."""
+    from rtk_amd.types import MeshSet, RTK_TYPE_U16
+    L = api.lib()
+    tris = synth.triangle_soup(500, 0.1, seed=3)
+    for builder in (0, 1):
+        ms = MeshSet([dict(positions=tris)])
+        ms._arr[0].position.type = RTK_TYPE_U16            # an index type where a position type belongs
+        L.rtk_amd_set_builder(builder)
+        try:
+            b = L.rtk_start_build(C.byref(ms.desc), None)
+            if b and builder == 0:
+                # the device builder runs inside the one task of its graph: the failure shows there or at the finish
+                s = L.rtk_finish_build(b)
+                assert not s
+            else:
+                assert not b
+            assert "type" in api.last_error()
+        finally:
+            L.rtk_amd_set_builder(0)
+    assert not L.rtk_dev_scene_build(C.byref(ms.desc)) and "type" in api.last_error()
+
+
+def test_planes_beyond_float_range_keep_the_scene_on_exact_nodes(api, oracle):
+    """A blob whose boxes reach +-3e38 (extent not finite in float) cannot be compressed to the 8-bit grid: the scene must
+    fall back to its exact nodes instead of storing wrapped planes that cull real hits."""
+    tris = synth.triangle_soup(400, 0.2, seed=9)
+    blob = oracle.build_scene([dict(positions=tris)])
+    data = blob.data.copy()
+    # stretch the root's child boxes: every finite plane of the root node becomes +-3e38 (a valid, huge box)
+    root = np.frombuffer(data, np.float32, 24, 128).copy().reshape(3, 2, 4)
+    occupied = root[:, 0, :] <= root[:, 1, :]
+    root[:, 0, :][occupied] = np.float32(-3.0e38)
+    root[:, 1, :][occupied] = np.float32(3.0e38)
+    data[128:128 + 96] = np.frombuffer(root.tobytes(), np.uint8)
+    ds = api.DeviceScene.upload(data)
+    rays = synth.rays_config1(4096)
+    rec_default = ds.trace(rays, full=False)
+    rec_exact = ds.trace(rays, opts=api.make_opts(exact_nodes=True), full=False)
+    assert rec_default.tobytes() == rec_exact.tobytes()
+    oh, om = oracle.trace(oracle.Blob(data), rays)
+    gm = rec_default["prim"] != 0xFFFFFFFF
+    assert (gm == om).all() and om.sum() > 100
