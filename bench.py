@@ -179,7 +179,11 @@ def main():
                     help="device = GPU LBVH build (product path); oracle-blob = upload a blob built by the CPU oracle (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-gather", action="store_true", help="N>1: leave hit records on their GPU")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave hit records on their GPU (same as --gather none)")
+    ap.add_argument("--gather", default="striped", choices=["striped", "root", "none"],
+                    help="N>1, what `value` includes: striped = every rank ends up with its stripe of every shard (all-to-all of record "
+                         "slices: no link carries more than 1/N of a shard per step); root = all records onto rank 0 (bound by the root's "
+                         "incoming links); none = records stay where they were traced. The other two are timed as well and reported in config.")
     ap.add_argument("--static", action="store_true", help="A/B: one fixed ray per lane instead of persistent refill")
     ap.add_argument("--no-tiling", action="store_true")
     ap.add_argument("--no-packet", action="store_true", help="A/B: image-shaped batch on the per-lane kernel")
@@ -329,8 +333,12 @@ def main():
     # two output buffers: with N > 1 the gather of step k overlaps the trace of step k+1
     d_outs = [torch.empty(n * out_bytes, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
     sizes = [n * out_bytes] * world
-    gather = world > 1 and not args.no_gather
-    gathered = [torch.empty(sum(sizes), dtype=torch.uint8, device=dev) if (gather and rank == 0) else None for _ in d_outs]
+    if args.no_gather:
+        args.gather = "none"
+    mode = args.gather if world > 1 else "none"
+    # receive buffers of the two exchanges (two each: the exchange of step k overlaps the trace of step k+1)
+    gathered = [torch.empty(sum(sizes), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None for _ in d_outs]
+    striped = [torch.empty(n * out_bytes, dtype=torch.uint8, device=dev) if world > 1 else None for _ in d_outs]
     pending = [[] for _ in d_outs]
 
     def trace(buf):
@@ -339,17 +347,20 @@ def main():
         else:
             ds.trace_device(d_rays, n, buf, opts)
 
-    def step(k, ev=None):
+    def step(k, ev=None, how=None):
+        how = how or mode
         b = k % len(d_outs)
-        shard.gather_records_wait(pending[b])       # this buffer's previous gather has drained
+        shard.gather_records_wait(pending[b])       # this buffer's previous exchange has drained
         pending[b] = []
         if ev:
             ev[0].record()                          # same stream the kernel is launched on
         trace(d_outs[b])
         if ev:
             ev[1].record()
-        if gather:
+        if how == "root":
             _, pending[b] = shard.gather_records_start(d_outs[b], sizes, dst=0, out=gathered[b])
+        elif how == "striped":
+            _, pending[b], _ = shard.exchange_striped_start(d_outs[b], out_bytes, out=striped[b])
 
     def drain():
         for b in range(len(d_outs)):
@@ -408,26 +419,30 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
-    elapsed_no_gather = None
+    other_modes = {}
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        if gather:
-            # the same K steps with the records left on their GPU: at ~7 Grays/s one GPU produces
-            # ~110 GB/s of hit records, more than one xGMI link direction carries, so the gather can
-            # be what bounds `value`; this second figure shows the traversal scaling by itself
+        # the same K steps under the other two treatments of the records, so that one line shows all three: a GPU that
+        # traces 16 Grays/s produces ~260 GB/s of records, one xGMI link direction carries ~77 GB/s, and a root takes in at
+        # most its 7 links -- what `value` includes decides what bounds it
+        for how in ("striped", "root", "none"):
+            if how == mode:
+                continue
             dist.barrier()
             sync()
             t1 = time.perf_counter()
             for k in range(args.steps):
-                trace(d_outs[k % len(d_outs)])
+                step(k, None, how)
+            drain()
             sync()
             dist.barrier()
             sync()
             t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-            elapsed_no_gather = float(t2.item())
+            other_modes[how] = float(t2.item())
+    elapsed_no_gather = other_modes.get("none")
     d_out = d_outs[(args.steps - 1) % len(d_outs)] if args.steps else d_outs[0]
 
     # ---- the result that was timed ---------------------------------------------------------
@@ -475,7 +490,12 @@ def main():
                    "bvh_build_ms_device_resident_mesh": round(build_ms_device_mesh, 2) if build_ms_device_mesh else None,
                    "bvh_build_mtris_s_device_resident_mesh": round(cfg["num_tris"] / build_ms_device_mesh / 1e3, 1) if build_ms_device_mesh else None,
                    "hit_fraction": round(hit_frac, 4),
-                   "gather": ("records to rank 0 over RCCL, overlapped with the next step's trace" if gather else None), "value_without_gather_mrays_s": round(n * world * args.steps / elapsed_no_gather / 1e6, 2) if elapsed_no_gather else None,
+                   "gather": {"striped": "every rank receives its stripe of every shard's records over RCCL (batched point-to-point, each link carries 1/N of a shard per step), overlapped with the next step's trace",
+                              "root": "all records onto rank 0 over RCCL (batched point-to-point), overlapped with the next step's trace; bound by the root's incoming links",
+                              "none": None}[mode],
+                   "value_without_gather_mrays_s": round(n * world * args.steps / elapsed_no_gather / 1e6, 2) if elapsed_no_gather else None,
+                   "value_root_gather_mrays_s": round(n * world * args.steps / other_modes["root"] / 1e6, 2) if "root" in other_modes else None,
+                   "value_striped_gather_mrays_s": round(n * world * args.steps / other_modes["striped"] / 1e6, 2) if "striped" in other_modes else None,
                    "launch": "static" if args.static else "persistent",
                    "ray_order": "RTK_TRACE_SORT_RAYS: re-ordered by origin cell inside every timed step" if args.sort_rays else "as given",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},

@@ -292,6 +292,52 @@ def gen_near_ties(tris, ulps=8):
     save("near_ties.npz", scene_sha256=sha(tris), ulps=np.int64(ulps), **out)
 
 
+def gen_tiny_t(tris, thresh=1e-6):
+    """tests/golden/tiny_t.npz: every ray of the FULL config-2 and config-3 batches whose closest hit lies at |t| < 1e-6
+    (a ray origin on, or a hair off, a triangle). There a relative tolerance on t means nothing -- the value is what is
+    left of a cancellation, and rtk.c's group-of-four rule (rtk.c:302-336) moves it by tens of percent with the leaf
+    grouping (round 2's bench line: max_rel_t 0.25 at t = 2.9e-8 between two BVHs) -- so the pin is exact: the REAL
+    rtk.c's (t, u, v) for the hit triangle, and for the next candidates behind it, under both groupings."""
+    blob = po.build_scene([dict(positions=tris)])
+    total = 4096 * 4096
+    out = {}
+    for name, make in (("cfg2", lambda a, n: synth.rays_pinhole(4096, 4096, first=a, count=n)),
+                       ("cfg3", lambda a, n: synth.rays_incoherent(n, first=a))):
+        t0 = time.time()
+        idxs, cands = [], []
+        chunk = 1 << 21
+        for a in range(0, total, chunk):
+            n = min(chunk, total - a)
+            rays = make(a, n)
+            h1, m1 = po.trace(blob, rays)
+            sel = np.nonzero(m1 & (np.abs(h1["t"]) < thresh))[0]
+            if sel.size == 0:
+                continue
+            cand = np.full((sel.size, 4), 0xFFFFFFFF, np.uint32)
+            cand[:, 0] = h1["triangle_index"][sel]
+            # the candidates right behind it (within the same threshold), as find_near_ties does
+            cur_t, cur_tri, sub, alive = h1["t"][sel].copy(), h1["triangle_index"][sel].copy(), rays[sel], np.ones(sel.size, bool)
+            for k in range(1, 4):
+                hk, mk = po.trace_filtered(blob, sub, after=(cur_t, np.where(alive, 0, 0xFFFFFFFF).astype(np.uint32), cur_tri))
+                alive = alive & mk & (np.abs(np.where(mk, hk["t"], 1)) < thresh)
+                cand[alive, k] = hk["triangle_index"][alive]
+                cur_t = np.where(alive, hk["t"], cur_t).astype(np.float32)
+                cur_tri = np.where(alive, hk["triangle_index"], cur_tri).astype(np.uint32)
+            idxs.append(sel.astype(np.int64) + a)
+            cands.append(cand)
+        idx = np.concatenate(idxs) if idxs else np.zeros(0, np.int64)
+        cand = np.concatenate(cands) if cands else np.zeros((0, 4), np.uint32)
+        rays = np.concatenate([make(int(i), 1) for i in idx]) if len(idx) else np.zeros(0, RAY_DTYPE)
+        hit, tuv = reference_values_both_groupings(tris, rays, cand)
+        print("  %s: %d rays with |t| < %g of %d (%.0f s)" % (name, len(idx), thresh, total, time.time() - t0))
+        out[name + "_ray_index"] = idx
+        out[name + "_rays"] = rays.view(np.float32).reshape(-1, 8)
+        out[name + "_cand_prim"] = cand
+        out[name + "_cand_hit"] = hit
+        out[name + "_cand_tuv"] = tuv
+    save("tiny_t.npz", scene_sha256=sha(tris), thresh=np.float64(thresh), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="edge,cfg1,cfg2,cfg3,cfg5")
@@ -309,10 +355,12 @@ def main():
         gen_cfg1()
     if "exotic" in only:
         gen_exotic()
-    if only & {"cfg2", "cfg3", "near_ties"}:
+    if only & {"cfg2", "cfg3", "near_ties", "tiny_t"}:
         tris = synth.scene_for_config(2)
         if "near_ties" in only:
             gen_near_ties(tris)
+        if "tiny_t" in only:
+            gen_tiny_t(tris)
         if "cfg2" in only:
             gen_cfg2(tris)
         if "cfg3" in only:

@@ -16,6 +16,8 @@
 
 #include <string.h>
 
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -109,19 +111,44 @@ extern "C" const rtk_dev_scene *rtk_mgpu_scene(const rtk_mgpu *m, int index)
 	return (m && index >= 0 && index < (int)m->slots.size()) ? m->slots[index].scene : nullptr;
 }
 
+// One host thread per device slot runs `work(slot index)`; the first failure's code and message (error strings are per
+// thread) come back to the caller. Slots that share a physical device (virtual shards) are run by one thread, in order.
+template <typename F>
+static int for_each_slot_in_parallel(rtk_mgpu *m, F work)
+{
+	const size_t R = m->slots.size();
+	std::vector<int> rcs(R, RTK_AMD_OK);
+	std::vector<std::string> msgs(R);
+	std::vector<std::thread> threads;
+	std::vector<bool> taken(R, false);
+	for (size_t i = 0; i < R; i++) {
+		if (taken[i]) continue;
+		std::vector<size_t> mine;
+		for (size_t j = i; j < R; j++) if (!taken[j] && m->slots[j].device == m->slots[i].device) { mine.push_back(j); taken[j] = true; }
+		threads.emplace_back([&, mine]() {
+			for (size_t j : mine) {
+				if (hipSetDevice(m->slots[j].device) != hipSuccess) { rcs[j] = RTK_AMD_ERR_NO_DEVICE; msgs[j] = "rtk_mgpu: hipSetDevice failed"; (void)hipGetLastError(); continue; }
+				rcs[j] = work(j);
+				if (rcs[j] != RTK_AMD_OK) msgs[j] = rtk_amd_last_error();
+			}
+		});
+	}
+	for (std::thread &t : threads) t.join();
+	for (size_t j = 0; j < R; j++) if (rcs[j] != RTK_AMD_OK) { rtk_set_error("device slot %zu: %s", j, msgs[j].c_str()); return rcs[j]; }
+	return RTK_AMD_OK;
+}
+
+// the scene on every GPU of the context: each device builds (or uploads) its own replica on a host thread of its own, so
+// eight replicas take the time of one
 static int replicate(rtk_mgpu *m, const rtk_scene_desc *desc, const rtk_scene *blob)
 {
 	if (!m) { rtk_set_error("rtk_mgpu: NULL context"); return RTK_AMD_ERR_BAD_ARG; }
-	int before = 0, rc = RTK_AMD_OK;
-	(void)hipGetDevice(&before);
-	for (DeviceSlot &s : m->slots) {
-		if (hipSetDevice(s.device) != hipSuccess) { rtk_set_error("rtk_mgpu: hipSetDevice(%d) failed", s.device); rc = RTK_AMD_ERR_NO_DEVICE; break; }
+	return for_each_slot_in_parallel(m, [&](size_t j) -> int {
+		DeviceSlot &s = m->slots[j];
 		if (s.scene) rtk_dev_scene_free(s.scene);
 		s.scene = desc ? rtk_dev_scene_build(desc) : rtk_dev_scene_upload(blob);
-		if (!s.scene) { rc = RTK_AMD_ERR_HIP; break; }
-	}
-	(void)hipSetDevice(before);
-	return rc;
+		return s.scene ? RTK_AMD_OK : RTK_AMD_ERR_HIP;
+	});
 }
 
 extern "C" int rtk_mgpu_build(rtk_mgpu *m, const rtk_scene_desc *desc)
@@ -187,29 +214,41 @@ extern "C" int rtk_mgpu_trace_rays(rtk_mgpu *m, const rtk_ray *rays, size_t n, r
 	if (!m || (!rays && n) || (!records && n)) { rtk_set_error("rtk_mgpu_trace_rays: NULL argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) return RTK_AMD_OK;
 	const int R = (int)m->slots.size();
-	int before = 0, rc = RTK_AMD_OK;
+	for (DeviceSlot &s : m->slots) if (!s.scene) { rtk_set_error("rtk_mgpu_trace_rays: no scene (call rtk_mgpu_build or rtk_mgpu_upload first)"); return RTK_AMD_ERR_BAD_ARG; }
+	int before = 0;
 	(void)hipGetDevice(&before);
-	for (int r = 0; r < R && rc == RTK_AMD_OK; r++) {
-		DeviceSlot &s = m->slots[r];
-		if (!s.scene) { rtk_set_error("rtk_mgpu_trace_rays: no scene (call rtk_mgpu_build or rtk_mgpu_upload first)"); rc = RTK_AMD_ERR_BAD_ARG; break; }
+	// an image-shaped batch (rows of `image_width` rays) stays image shaped on a shard that is a whole number of 8-row
+	// tile rows -- e.g. eight frames on eight GPUs --, so that every GPU runs the packet kernels, not only a lone one
+	const bool image = opts && opts->struct_size >= 16 && opts->image_width && opts->image_height &&
+		(size_t)opts->image_width * opts->image_height == n && opts->image_width % 8u == 0;
+	// one host thread per device: its shard's rays go up (pageable host memory: the copy is the host's work), are traced in
+	// pieces, and the records of each piece come back while the next piece is traced
+	int rc = for_each_slot_in_parallel(m, [&](size_t j) -> int {
+		DeviceSlot &s = m->slots[j];
 		size_t first, count;
-		rtk_amd_shard_range(n, r, R, &first, &count);
-		if (count == 0) continue;
-		if (hipSetDevice(s.device) != hipSuccess) { rc = RTK_AMD_ERR_NO_DEVICE; break; }
+		rtk_amd_shard_range(n, (int)j, R, &first, &count);
+		if (count == 0) return RTK_AMD_OK;
 		if (s.cap < count) {
 			if (s.d_rays) (void)hipFree(s.d_rays);
 			if (s.d_rec) (void)hipFree(s.d_rec);
 			s.d_rays = nullptr; s.d_rec = nullptr; s.cap = 0;
 			if (hipMalloc(&s.d_rays, count * sizeof(rtk_ray)) != hipSuccess || hipMalloc(&s.d_rec, count * sizeof(rtk_hit_record)) != hipSuccess) {
 				rtk_set_error("rtk_mgpu_trace_rays: out of device memory on device %d", s.device);
-				rc = RTK_AMD_ERR_OOM; break;
+				return RTK_AMD_ERR_OOM;
 			}
 			s.cap = count;
 		}
-		if (hipMemcpyAsync(s.d_rays, rays + first, count * sizeof(rtk_ray), hipMemcpyHostToDevice, s.trace_stream) != hipSuccess) { rtk_set_error("rtk_mgpu_trace_rays: H2D copy failed"); rc = RTK_AMD_ERR_HIP; break; }
-		// the whole batch is image shaped only if there is a single shard
-		rc = trace_shard(s, s.d_rays, count, s.d_rec, records + first, -1, true, R == 1 ? opts : nullptr);
-	}
+		if (hipMemcpyAsync(s.d_rays, rays + first, count * sizeof(rtk_ray), hipMemcpyHostToDevice, s.trace_stream) != hipSuccess) { rtk_set_error("rtk_mgpu_trace_rays: H2D copy failed"); return RTK_AMD_ERR_HIP; }
+		rtk_trace_opts shard_opts;
+		const rtk_trace_opts *so = nullptr;
+		if (image && first % ((size_t)opts->image_width * 8u) == 0 && count % ((size_t)opts->image_width * 8u) == 0) {
+			memset(&shard_opts, 0, sizeof(shard_opts));
+			memcpy(&shard_opts, opts, opts->struct_size < sizeof(shard_opts) ? opts->struct_size : sizeof(shard_opts));
+			shard_opts.image_height = (uint32_t)(count / opts->image_width);
+			so = &shard_opts;
+		} else if (opts && !image) so = opts;
+		return trace_shard(s, s.d_rays, count, s.d_rec, records + first, -1, true, so);
+	});
 	const int frc = finish_all(m);
 	(void)hipSetDevice(before);
 	return rc != RTK_AMD_OK ? rc : frc;

@@ -780,8 +780,11 @@ LaunchScratch *scratch_for(rtk_dev_scene *ds, hipStream_t stream)
 	for (LaunchScratch *s : ds->scratch) if (s->stream == stream) return s;
 	LaunchScratch *s = new LaunchScratch();
 	s->stream = stream;
+	// (cleared ON THE LAUNCH STREAM: a hipMemset goes to the NULL stream, which non-blocking streams do not wait for -- behind
+	// another thread's device build there it ran milliseconds late, and a first launch read a stale error word: an intermittent
+	// "traversal stack overflow" in test_builds_and_traces_from_several_threads_at_once)
 	if (hipMalloc(&s->d_counter, (RTK_COUNTER_WORDS + 1) * sizeof(unsigned long long)) != hipSuccess ||
-		hipMemset(s->d_counter, 0, (RTK_COUNTER_WORDS + 1) * sizeof(unsigned long long)) != hipSuccess) {
+		hipMemsetAsync(s->d_counter, 0, (RTK_COUNTER_WORDS + 1) * sizeof(unsigned long long), stream) != hipSuccess) {
 		rtk_set_error("rtk_dev_trace: out of device memory (launch scratch)");
 		delete s;
 		return nullptr;

@@ -52,3 +52,50 @@ def gather_records(local, sizes, dst=0, group=None):
     out, works = gather_records_start(local, sizes, dst, group)
     gather_records_wait(works)
     return out
+
+
+def stripe_bounds(n_records, world):
+    """[begin, end) in records of the world's stripes of one shard of n_records (the same floor rule as shard_range)."""
+    return [shard_range(n_records, j, world) for j in range(world)]
+
+
+def exchange_striped_start(local, record_bytes, group=None, out=None):
+    """The gather that no single link funnels: every rank ends up with stripe `rank` of EVERY shard (an all-to-all of
+    record slices) instead of rank 0 ending up with everything.
+
+    Why: a GPU that traces 16 Grays/s produces ~260 GB/s of 16-byte records, one xGMI link carries ~77 GB/s per
+    direction and a root takes in at most its 7 links (~0.54 TB/s): gathered onto ONE GPU, eight shards can never
+    arrive faster than ~34 Grays/s in total, however the copies are scheduled. Striped, each rank sends 1/world of
+    its shard over each of its links and receives as much: per link and step 1/world of a shard, so the exchange
+    hides behind the next step's trace. The whole result then lives striped across the GPUs (out[r-th segment] =
+    stripe `rank` of rank r's shard, segments in rank order) -- where a distributed consumer wants it, and from where
+    eight PCIe links can take it to the host at once.
+
+    `local`: this rank's records as a flat uint8 tensor (a multiple of record_bytes). Point-to-point, issued as ONE
+    batch. Returns (out, works, segments): segments[r] = (begin, end) in bytes of rank r's contribution inside `out`;
+    gather_records_wait(works) before touching `out` or overwriting `local`."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_rec = local.numel() // record_bytes
+    if world == 1:
+        return local, [], [(0, local.numel())]
+    # every rank's shard size (in records) -- the segments of `out` need them; equal shards need no exchange of sizes
+    counts = [n_rec] * world
+    mine = [stripe_bounds(c, world)[rank] for c in counts]          # my stripe of rank r's shard, in records of that shard
+    seg, at = [], 0
+    for b, e in mine:
+        seg.append((at, at + (e - b) * record_bytes))
+        at += (e - b) * record_bytes
+    if out is None:
+        out = torch.empty(at, dtype=local.dtype, device=local.device)
+    ops = []
+    for j, (b, e) in enumerate(stripe_bounds(n_rec, world)):
+        piece = local[b * record_bytes:e * record_bytes]
+        if j == rank:
+            out[seg[rank][0]:seg[rank][1]].copy_(piece, non_blocking=True)
+        elif e > b:
+            ops.append(dist.P2POp(dist.isend, piece, j, group))
+    for r in range(world):
+        if r != rank and seg[r][1] > seg[r][0]:
+            ops.append(dist.P2POp(dist.irecv, out[seg[r][0]:seg[r][1]], r, group))
+    return out, (dist.batch_isend_irecv(ops) if ops else []), seg

@@ -95,6 +95,42 @@ def test_pipelined_gather_two_ranks(tmp_path):
     assert open(out).read() == "ok"
 
 
+def _striped_worker(rank, world, port, n, out_path):
+    sys.path.insert(0, ROOT)
+    from rtk_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank r's shard: record i of it is 16 bytes holding (r, i)
+    def shard_of(r):
+        a = np.zeros((n, 4), np.uint32)
+        a[:, 0] = r
+        a[:, 1] = np.arange(n)
+        return a
+    local = torch.from_numpy(shard_of(rank).view(np.uint8).reshape(-1).copy())
+    out, works, seg = shard.exchange_striped_start(local, 16)
+    shard.gather_records_wait(works)
+    got = out.numpy().view(np.uint32).reshape(-1, 4)
+    ok = True
+    at = 0
+    for r in range(world):
+        b, e = shard.stripe_bounds(n, world)[rank]
+        want = shard_of(r)[b:e]
+        ok = ok and seg[r] == (at * 16, (at + e - b) * 16) and (got[at:at + e - b] == want).all()
+        at += e - b
+    ok = ok and at == len(got)
+    dist.barrier()
+    open(out_path + str(rank), "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_striped_exchange_three_ranks(tmp_path):
+    """The exchange that replaces the gather onto one root: every rank ends up with its stripe of every shard."""
+    out = str(tmp_path / "result")
+    mp.spawn(_striped_worker, args=(3, _free_port(), 1001, out), nprocs=3, join=True)
+    assert [open(out + str(r)).read() for r in range(3)] == ["ok"] * 3
+
+
 def test_bench_multi_rank_plumbing_dry_run():
     """bench.py's N=2 control flow (env ranks, gloo, double-buffered gather, barrier/max timing, one
     JSON line from rank 0) with the tracer replaced by a stand-in: catches plumbing errors that the
@@ -110,5 +146,5 @@ def test_bench_multi_rank_plumbing_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["gather"] and d["config"]["value_without_gather_mrays_s"] > 0
+    assert "stripe" in d["config"]["gather"] and d["config"]["value_without_gather_mrays_s"] > 0 and d["config"]["value_root_gather_mrays_s"] > 0
     assert "dry-run" in d["data"]
