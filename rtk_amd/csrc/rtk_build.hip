@@ -18,6 +18,7 @@
 //                LDS, then the nodes that cross tile borders with memory-side atomics
 //   8 collapse   breadth-first, level by level: binary tree -> 128 B 4-wide nodes
 #include "rtk_dev.h"
+#include "rtk_node_finish.h"
 
 #include <limits.h>
 #include <math.h>
@@ -151,10 +152,10 @@ __global__ void __launch_bounds__(INGEST_BLOCK) k_ingest(const char *pos, unsign
 
 template <int IDX>
 void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
-	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris, uint32_t *bounds)
+	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris, uint32_t *bounds, hipStream_t stream)
 {
-	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(INGEST_BLOCK), 0, 0, pos, pstride, idx, istride, nt, base, in_tris, bounds);
-	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(INGEST_BLOCK), 0, 0, pos, pstride, idx, istride, nt, base, in_tris, bounds);
+	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, bounds);
+	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, bounds);
 }
 
 // ---------------------------------------------------------------------------------- 2 bounds
@@ -528,6 +529,72 @@ __device__ __forceinline__ BinNode combine_records(const BinNode &a, const BinNo
 	return out;
 }
 
+#define REFIT_TILE 1024
+#define REFIT_BLOCK 1024        // one thread per triangle: every global load of the tile is in flight at once
+
+// ---- tile-local collapse (binary -> 4-wide) shared by the counting tail of k_refit_tile and by k_collapse_tile ----
+// A binary node whose sorted range lies inside one tile (a node pass 1 finishes) is never opened INSIDE a wide node that
+// lies above the tile: the maximal such subtrees ("tile roots") always become wide nodes of their own, so everything
+// below them can be collapsed by the tile's workgroup alone, out of LDS, while the few nodes above (the ones pass 2
+// finishes) go through the level-by-level collapse. Costs ~1 % more node visits than the unconstrained greedy collapse
+// (scripts/bvh_lab.cpp -ft 1024) and replaces a dozen launches of dependent random reads over the whole tree.
+//
+// Chooses the (up to four) children of wide-node job b, a tile-contained binary node: its two children, then twice the
+// largest-area child that is still an openable inner node -- the rule of collapse_open below, on LDS copies of the
+// tile's child links and areas (lr_, area_ indexed by node - lo; open_area).
+__device__ __forceinline__ int tile_open(int b, int lo, const int2 *lr_, const float *area_, int c[4])
+{
+	const int2 ch = lr_[b - lo];
+	c[0] = ch.x; c[1] = ch.y; c[2] = 0; c[3] = 0;
+	int nc = 2;
+#pragma unroll
+	for (int round = 0; round < 2; round++) {
+		int best = -1;
+		float best_area = 0.0f;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if (k >= nc || c[k] < 0) continue;
+			const float a = area_[c[k] - lo];                              // <= 0: one leaf, not opened
+			if (a > best_area) { best_area = a; best = k; }
+		}
+		if (best >= 0) {
+			int bref = 0;
+#pragma unroll
+			for (int k = 0; k < 4; k++) if (k == best) bref = c[k];
+			const int2 o = lr_[bref - lo];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				if (k == best) c[k] = o.x;
+				if (k == nc) c[k] = o.y;
+			}
+			nc++;
+		}
+	}
+	return nc;
+}
+
+// what tile_open ranks openable children by: the half area of the node's box, never zero (a box flat on two axes must stay
+// openable); negative for a subtree the SAH rule turned into one leaf
+__device__ __forceinline__ float open_area(const BinNode &r)
+{
+	return (r.cnt_flag & 0x80000000u) ? -1.0f : fmaxf(half_area(r.mn, r.mx), 1e-37f);
+}
+
+// exclusive prefix sum of `v` over the threads of the workgroup (at most 1024; s_w: 16 words of LDS); *total = the sum
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *s_w, uint32_t *total)
+{
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+	uint32_t inc = v;
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+	__syncthreads();                                   // s_w may still be read from the previous use
+	if (lane == 63u) s_w[wave] = inc;
+	__syncthreads();
+	uint32_t off = 0, tot = 0;
+	for (uint32_t w = 0; w < waves; w++) { if (w < wave) off += s_w[w]; tot += s_w[w]; }
+	*total = tot;
+	return off + inc - v;
+}
+
 // Pass 1, tile-local. The sorted triangles are cut into tiles of REFIT_TILE; one 1024-thread workgroup owns a tile and
 // builds every inner node whose two children lie inside it (split positions lo .. hi-1 with ranges inside [lo, hi]):
 // similarities, child links, range ends, arrival counters and the 32-B node records of the tile live in LDS, so a climb
@@ -535,25 +602,22 @@ __device__ __forceinline__ BinNode combine_records(const BinNode &a, const BinNo
 // all-global version of round 1 cost ~14 memory-side atomics per node, 3.8 ms at 10M triangles). Finished nodes are
 // written out once, coalesced. A subtree whose parent lies across the tile border is left for pass 2 as a "climber":
 // (subtree, L, R), stored at the leaf that carried it.
-#define REFIT_TILE 1024
-#define REFIT_BLOCK 1024        // one thread per triangle: every global load of the tile is in flight at once
 
 struct Climb { int cur_ref; int l; int r; };      // cur_ref: >= 0 inner node, < 0 leaf ~slot; INT_MIN: none
 
 __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
-	BinNode *bin, Climb *climbers, unsigned long long *half, uint32_t *arrive, int *root, BuildParams bp)
+	BinNode *bin, Climb *climbers, unsigned long long *half, uint32_t *arrive, int *root, BuildParams bp, float *area)
 {
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
 	__shared__ uint32_t s_arrive[REFIT_TILE];
-	__shared__ int s_left[REFIT_TILE], s_right[REFIT_TILE];     // children of node lo + k
+	__shared__ int2 s_lr[REFIT_TILE];                            // children of node lo + k (x left, y right)
 	__shared__ int s_rl[REFIT_TILE], s_rr[REFIT_TILE];          // its range
 	__shared__ int s_delta[REFIT_TILE + 1];                     // [k] = similarity across the border between lo+k-1 and lo+k
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
 	const int t = (int)threadIdx.x;
 	s_arrive[t] = 0u;
-	s_left[t] = INT_MIN;
-	s_right[t] = INT_MIN;
+	s_lr[t] = make_int2(INT_MIN, INT_MIN);
 	if (lo + t - 1 <= hi) s_delta[t] = key_delta(keys, n, lo + t - 1);
 	if (t == 0 && hi - lo + 1 == REFIT_TILE) s_delta[REFIT_TILE] = key_delta(keys, n, hi);
 	__syncthreads();
@@ -573,11 +637,11 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 				break;
 			}
 			const int k = parent - lo;
-			if (go_right) { s_left[k] = cur_ref; s_rl[k] = L; } else { s_right[k] = cur_ref; s_rr[k] = R; }
+			if (go_right) { s_lr[k].x = cur_ref; s_rl[k] = L; } else { s_lr[k].y = cur_ref; s_rr[k] = R; }
 			// (cur, if it is an inner node, sits in s_bin[cur_ref - lo] already: LDS is in order, the arrival below publishes it)
 			const uint32_t old = __hip_atomic_fetch_add(&s_arrive[k], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (old == 0u) break;                                            // first arriver: the sibling's thread carries on
-			const int sib = go_right ? s_right[k] : s_left[k];
+			const int sib = go_right ? s_lr[k].y : s_lr[k].x;
 			if (go_right) R = s_rr[k]; else L = s_rl[k];
 			const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : s_bin[sib - lo];
 			cur = combine_records(cur, other, bp);
@@ -589,16 +653,33 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	__syncthreads();
 	if (i < hi && s_arrive[t] == 2u) {
 		bin[i] = s_bin[t];
-		lr[i] = make_int2(s_left[t], s_right[t]);
+		if (area) area[i] = open_area(s_bin[t]);      // what the tile-local collapse ranks children by (4 bytes instead of the 32-byte record)
+		lr[i] = s_lr[t];
 		range[i] = make_uint2((uint32_t)s_rl[t], (uint32_t)s_rr[t]);
 	} else if (i < hi && s_arrive[t] == 1u) {
 		// one child came, the other one's subtree reaches into a neighbouring tile and arrives in pass 2: hand the half that
 		// is here over in the form pass 2 uses (plain stores, the kernel boundary publishes them)
-		const bool left_here = s_left[t] != INT_MIN;
-		const int ref = left_here ? s_left[t] : s_right[t], end = left_here ? s_rl[t] : s_rr[t];
+		const bool left_here = s_lr[t].x != INT_MIN;
+		const int ref = left_here ? s_lr[t].x : s_lr[t].y, end = left_here ? s_rl[t] : s_rr[t];
 		half[2 * (size_t)i + (left_here ? 0 : 1)] = ((unsigned long long)(uint32_t)ref << 32) | (uint32_t)end;
 		arrive[i] = 1u;
 	}
+}
+
+// exclusive prefix sums of the tiles' wide-node counts (one workgroup; a build has at most n / 1024 tiles); out[num] = total
+__global__ void __launch_bounds__(1024) k_scan_tiles(const uint32_t *count, uint32_t num, uint32_t *base)
+{
+	__shared__ uint32_t s_w[16];
+	uint32_t carry = 0;
+	for (uint32_t at = 0; at < num; at += 1024u) {
+		const uint32_t i = at + threadIdx.x;
+		const uint32_t v = i < num ? count[i] : 0u;
+		uint32_t total = 0;
+		const uint32_t ex = block_exclusive_scan_1024(v, s_w, &total);
+		if (i < num) base[i] = carry + ex;
+		carry += total;
+	}
+	if (threadIdx.x == 0) base[num] = carry;
 }
 
 // Pass 2: the few nodes whose children lie in different tiles (about two per tile plus chains). The hand-off of the
@@ -634,8 +715,12 @@ __device__ __forceinline__ BinNode bin_load(BinNode *src)
 }
 
 // half[node] = { left child | left range end , right child | right range end }: each half one 8-byte word
+// never_leaf (tile mode): a node finished here -- one that reaches across a tile border -- is never ONE leaf. Its finished
+// children are the roots that k_collapse_tile turns into wide nodes (k_refit_tile counted them before this pass knew the
+// node's cost), so the node above them must stay a node: a leaf of two or three triangles straddling a border would
+// otherwise swallow a subtree that already has a number. (One such node at 17M triangles; found by the validator.)
 __global__ void k_refit_top(const DevTri *tris, int n, const unsigned long long *keys, const Climb *climbers, unsigned long long *half,
-	uint32_t *arrive, BinNode *bin, int2 *lr, uint2 *range, int *root, BuildParams bp)
+	uint32_t *arrive, BinNode *bin, int2 *lr, uint2 *range, int *root, BuildParams bp, bool never_leaf)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -660,6 +745,7 @@ __global__ void k_refit_top(const DevTri *tris, int n, const unsigned long long 
 		if (go_right) R = (int)(uint32_t)theirs; else L = (int)(uint32_t)theirs;
 		const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : bin_load(&bin[sib]);
 		cur = combine_records(cur, other, bp);
+		if (never_leaf) cur.cnt_flag &= 0x7fffffffu;
 		bin_store(&bin[parent], cur);
 		// topology of the finished node: read by the collapse only (later launches), plain stores
 		lr[parent] = go_right ? make_int2(cur_ref, sib) : make_int2(sib, cur_ref);
@@ -710,13 +796,18 @@ struct Cand {
 	int ref;          // binary child: >= 0 inner, < 0 leaf ~slot
 	float area;       // > 0 only if the child may still be opened
 	float mn[3], mx[3];
+	bool tile_job;    // tile mode: an inner node inside one refit tile -- a wide node that k_collapse_tile makes, not opened here
 };
 
-__device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin, const DevTri *tris)
+// The subtree is left alone by the level-by-level collapse if it lies inside one refit tile (tile mode).
+__device__ __forceinline__ bool in_one_tile(const uint2 rg) { return rg.x / REFIT_TILE == rg.y / REFIT_TILE; }
+
+__device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin, const DevTri *tris, const uint2 *range, bool tile_mode)
 {
 	Cand c;
 	c.ref = ref;
 	c.area = -1.0f;
+	c.tile_job = false;
 	if (ref >= 0) {
 		const BinNode b = bin[ref];
 		c.mn[0] = b.mn[0]; c.mn[1] = b.mn[1]; c.mn[2] = b.mn[2];
@@ -724,16 +815,30 @@ __device__ __forceinline__ Cand make_cand(int ref, const BinNode *bin, const Dev
 		// An inner node that is not one leaf can always be opened; the area only ranks the candidates. It can be ZERO
 		// (a box flat on two axes: triangles in a row, or extents that underflow) -- taking "area > 0" for "may be opened"
 		// turned such subtrees into single leaves of any size, which the 6-bit leaf count of the blob cannot even hold.
-		if (!(b.cnt_flag & 0x80000000u)) c.area = fmaxf(half_area(b.mn, b.mx), 1e-37f);
+		if (!(b.cnt_flag & 0x80000000u)) {
+			if (tile_mode && in_one_tile(range[ref])) c.tile_job = true;
+			else c.area = fmaxf(half_area(b.mn, b.mx), 1e-37f);
+		}
 	} else tri_box(tris, (uint32_t)~ref, c.mn, c.mx);
 	return c;
 }
 
+// a subtree the SAH rule turned into one leaf of the sorted triangles [rg.x, rg.y]: the count goes into its first record,
+// and only the last one keeps the end mark (every record starts out as a leaf of its own, k_emit_tris)
+__device__ __forceinline__ void mark_leaf(DevTri *tris, const uint2 rg)
+{
+	tris[rg.x].spare = rg.y - rg.x + 1u;
+	for (uint32_t t = rg.x; t < rg.y; t++) { tris[t].flags &= ~RTK_TRI_LAST; tris[t + 1u].spare = 0u; }
+}
+
 // Opens binary node b as wide node `node_index`: chooses its (up to four) children and writes the node except for the
 // numbers of the children that are wide nodes themselves. Returns how many those are.
+// tile_parent != NULL: tile mode. Children that are tile jobs keep an empty child word for now; where that word is (node,
+// slot) and the level of this node go to tile_parent[child], for k_collapse_tile to fill in.
 __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, const int2 *lr, const uint2 *range, const BinNode *bin,
-	DevTri *tris, DevNode *nodes, uint32_t node_cap, int4 &dec, uint32_t &info)
+	DevTri *tris, DevNode *nodes, uint32_t node_cap, int4 &dec, uint32_t &info, unsigned long long *tile_parent = nullptr, uint32_t level = 0)
 {
+	const bool tile_mode = tile_parent != nullptr;
 	Cand c[4];
 	int nc;
 	const BinNode self = bin[b];
@@ -742,11 +847,12 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 		c[0].ref = b; c[0].area = -1.0f;
 		c[0].mn[0] = self.mn[0]; c[0].mn[1] = self.mn[1]; c[0].mn[2] = self.mn[2];
 		c[0].mx[0] = self.mx[0]; c[0].mx[1] = self.mx[1]; c[0].mx[2] = self.mx[2];
+		c[0].tile_job = false;
 		nc = 1;
 	} else {
 		const int2 ch = lr[b];
-		c[0] = make_cand(ch.x, bin, tris);
-		c[1] = make_cand(ch.y, bin, tris);
+		c[0] = make_cand(ch.x, bin, tris, range, tile_mode);
+		c[1] = make_cand(ch.y, bin, tris, range, tile_mode);
 		nc = 2;
 		// (every index into c[] below is a compile-time constant after unrolling: a run-time index would put the 32-dword
 		// array into scratch memory, which made this function several times slower)
@@ -758,7 +864,7 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 			for (int k = 0; k < 4; k++) if (k < nc && c[k].area > best_area) { best_area = c[k].area; best = k; best_ref = c[k].ref; }
 			if (best >= 0) {
 				const int2 o = lr[best_ref];
-				const Cand left = make_cand(o.x, bin, tris), right = make_cand(o.y, bin, tris);
+				const Cand left = make_cand(o.x, bin, tris, range, tile_mode), right = make_cand(o.y, bin, tris, range, tile_mode);
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					if (k == best) c[k] = left;
@@ -788,12 +894,12 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 			mask |= 1u << k;
 			n_inner++;
 			r[k] = ref;                                           // binary reference; becomes a node number when this level is numbered
+		} else if (c[k].tile_job) {
+			r[k] = (int)RTK_REF_NONE;                             // k_collapse_tile writes the number of the wide node it makes of it
+			tile_parent[ref] = ((unsigned long long)level << 34) | ((unsigned long long)node_index << 2) | (unsigned long long)k;
 		} else {
-			// a subtree the SAH rule turned into one leaf: the count goes into its first record, and only the last one
-			// keeps the end mark
 			const uint2 rg = range[ref];
-			tris[rg.x].spare = rg.y - rg.x + 1u;
-			for (uint32_t t = rg.x; t < rg.y; t++) { tris[t].flags &= ~RTK_TRI_LAST; tris[t + 1u].spare = 0u; }
+			mark_leaf(tris, rg);
 			r[k] = (int)(RTK_REF_LEAF | rg.x);
 		}
 		out[0 + k] = c[k].mn[0]; out[4 + k] = c[k].mx[0];
@@ -847,7 +953,7 @@ __device__ __forceinline__ LevelState next_level(const LevelState &L, uint32_t n
 }
 
 __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B, const LevelState *ring, uint32_t step, const int2 *lr, const uint2 *range,
-	const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap)
+	const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, unsigned long long *tile_parent)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
 	const LevelState L = ring[step % COLLAPSE_RING];
@@ -858,7 +964,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B
 		if (j < count) {
 			int4 d;
 			uint32_t inf;
-			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, node_cap, d, inf);
+			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, node_cap, d, inf, tile_parent, L.level);
 			B.dec[j] = d;
 			B.info[j] = inf;
 		}
@@ -925,7 +1031,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs
 // that is already opened (dec/info valid) and hands over one that is opened too, block sums included. Launch 0 of a
 // build opens the root first.
 __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs B, LevelState *ring, uint32_t step, uint32_t max_levels,
-	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root)
+	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root, unsigned long long *tile_parent)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
 	__shared__ int s_ref[COLLAPSE_SMALL * 4];
@@ -937,7 +1043,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		if (threadIdx.x == 0) {
 			int4 d;
 			uint32_t inf;
-			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, node_cap, d, inf);
+			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, node_cap, d, inf, tile_parent, 0u);
 			B.dec[0] = d;
 			B.info[0] = inf;
 		}
@@ -965,7 +1071,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		for (uint32_t i = threadIdx.x; i < total; i += COLLAPSE_SMALL) {
 			int4 d2;
 			uint32_t inf2;
-			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, node_cap, d2, inf2);
+			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, node_cap, d2, inf2, tile_parent, N.level);
 			B.dec[i] = d2;
 			B.info[i] = inf2;
 			if (n2) atomicAdd(&s_sums[i / COLLAPSE_BLOCK], n2);
@@ -979,6 +1085,223 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = L;
+}
+
+// The tile-local collapse: a SMALL workgroup per refit tile turns the tile's forest of finished binary subtrees into
+// 4-wide nodes, out of LDS. Small on purpose: what a tile needs is a dozen rounds of a few dependent LDS reads each (which
+// binary nodes become wide nodes is marked top-down from the tile roots, one level per round) -- latency, not throughput --
+// so the chip is filled with many tiles at once (21 KB of LDS and one wave each: seven or more per CU) rather than with
+// many threads per tile (a 1024-thread workgroup per tile left 90 % of its lanes waiting at barriers: 1.5 ms at 10M
+// triangles; the level-by-level collapse over the whole tree, which this replaces, took 1.05 + 0.29 ms).
+//   k_count_tile     marks, and counts the tile's wide nodes; a prefix sum over the counts (k_scan_tiles) gives every tile
+//                    the number of its first node
+//   k_collapse_tile  marks again (same code, same result), numbers the tile's wide nodes in pre-order and writes each of
+//                    them ONCE and complete: boxes (the records pass 1 wrote), final child numbers, front-to-back order
+//                    words and the 64-byte compressed copy (k_quantize would re-read what was just written). Dense: thread
+//                    j makes node j of the tile. The roots of the forest are children of nodes the level-by-level collapse
+//                    made before: their numbers are written into those nodes' child words.
+#define TILE_THREADS 256       // k_collapse_tile: the first wave marks and numbers, all four finish nodes (k_count_tile: one wave)
+
+// loads the tile's child links and areas into LDS and lists the tile roots (s_roots, *s_nroots; their order does not matter:
+// numbers come from the tree alone): for every node / triangle position of the tile the subtree a triangle carried to the
+// border in pass 1 (its parent's split position lies outside the tile) and the finished child of a node that reaches beyond
+// the tile (its other child arrived in pass 2). Roots are inner nodes with disjoint ranges: at most REFIT_TILE / 2 of them.
+__device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers,
+	int2 *s_lr, float *s_area, uint16_t *s_start, int *s_roots, uint32_t *s_nroots)
+{
+	const int t = (int)threadIdx.x;
+	if (t == 0) *s_nroots = 0u;
+	for (int k = t; k < REFIT_TILE; k += (int)blockDim.x) {
+		const int i = lo + k;
+		uint2 rg = make_uint2((uint32_t)lo, (uint32_t)lo);
+		float a = -1.0f;
+		if (i < hi) { s_lr[k] = lr[i]; a = area[i]; rg = range[i]; }      // (entries of nodes that are not inside the tile are never followed)
+		else s_lr[k] = make_int2(INT_MIN, INT_MIN);
+		// a node that reaches beyond the tile is marked by an area of -2 for the second step below (it is never opened here)
+		s_area[k] = (i < hi && ((int)rg.x < lo || (int)rg.y > hi)) ? (((int)rg.x >= lo) ? -2.0f : -3.0f) : a;
+		if (s_start) s_start[k] = (uint16_t)((int)rg.x >= lo ? (int)rg.x - lo : 0);
+	}
+	__syncthreads();
+	for (int k = t; k < REFIT_TILE; k += (int)blockDim.x) {
+		const int i = lo + k;
+		if (i <= hi) {
+			const int a = climbers[i].cur_ref;
+			if (a >= 0 && s_area[a - lo] > 0.0f) s_roots[atomicAdd(s_nroots, 1u)] = a;
+		}
+		if (i < hi && s_area[k] <= -2.0f) {
+			const int2 ch = s_lr[k];
+			// (left child: sorted range [start, i]; right child: [i + 1, end]. At most one of them lies inside the tile: the
+			// left one if the node's range starts inside the tile (-2), else the right one if it ends inside (-3, checked by the
+			// child's own record: a child that reaches beyond the tile carries a mark itself))
+			const int half_ref = s_area[k] == -2.0f ? ch.x : ch.y;
+			if (half_ref >= 0 && half_ref >= lo && half_ref < hi && s_area[half_ref - lo] > 0.0f) s_roots[atomicAdd(s_nroots, 1u)] = half_ref;
+		}
+	}
+	__syncthreads();
+}
+
+// Which binary nodes of the tile become wide nodes ("jobs"): breadth-first from the tile roots, by ONE wave (the first of the
+// workgroup; the others wait at the caller's barrier) -- a level is a handful to a few hundred jobs, each a chain of four
+// dependent LDS reads, so what counts is not to touch anything but the jobs: s_q[0 .. count) lists them level by level
+// (node - lo), appended with the wave's own prefix sums (ballots), no barriers, no scan over the tile's 1024 positions per
+// level (that form of this loop took 100 us per tile). Returns count.
+//   s_spine / s_lvl / s_cnt may be NULL (counting only). s_spine[k]: how many jobs above node lo + k share its range start;
+//   s_cnt (packed 16-bit counters): jobs per range start; with these two the caller numbers the jobs in the PRE-ORDER of
+//   the forest (range start ascending, larger range first): every node after its parent, subtrees contiguous, numbers that
+//   depend on the tree alone. s_lvl[k]: level of the node in the whole tree (roots: level of the node above + 1, tile_parent).
+__device__ __forceinline__ uint32_t tile_bfs(int lo, const int2 *s_lr, const float *s_area, const uint16_t *s_start, const int *s_roots, uint32_t nroots,
+	const unsigned long long *tile_parent, uint16_t *s_q, uint16_t *s_spine, uint8_t *s_lvl, uint32_t *s_cnt)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	for (uint32_t r = lane; r < nroots; r += 64u) {
+		const int k = s_roots[r] - lo;
+		s_q[r] = (uint16_t)k;
+		if (s_spine) {
+			s_spine[k] = 0u;
+			const uint32_t l = (uint32_t)(tile_parent[s_roots[r]] >> 34) + 1u;
+			s_lvl[k] = (uint8_t)(l < 255u ? l : 255u);
+			atomicAdd(s_cnt + ((uint32_t)s_start[k] >> 1), (s_start[k] & 1u) ? 0x10000u : 1u);
+		}
+	}
+	uint32_t begin = 0, end = nroots, tail = nroots;
+	while (begin < end) {
+		for (uint32_t j0 = begin; j0 < end; j0 += 64u) {
+			const uint32_t j = j0 + lane;
+			int c[4] = { -1, -1, -1, -1 };
+			int nc = 0, t = 0;
+			if (j < end) { t = (int)s_q[j]; nc = tile_open(lo + t, lo, s_lr, s_area, c); }
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const bool inner = k < nc && c[k] >= 0 && s_area[c[k] - lo] > 0.0f;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(inner);
+				if (inner) {
+					const uint32_t pos = tail + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+					const int ck = c[k] - lo;
+					s_q[pos] = (uint16_t)ck;
+					if (s_spine) {
+						s_spine[ck] = s_start[ck] == s_start[t] ? (uint16_t)(s_spine[t] + 1u) : (uint16_t)0u;
+						s_lvl[ck] = (uint8_t)(s_lvl[t] < 255u ? s_lvl[t] + 1u : 255u);
+						atomicAdd(s_cnt + ((uint32_t)s_start[ck] >> 1), (s_start[ck] & 1u) ? 0x10000u : 1u);
+					}
+				}
+				tail += (uint32_t)__builtin_popcountll(m);
+			}
+		}
+		begin = end;
+		end = tail;
+	}
+	return tail;
+}
+
+__global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers, uint32_t *tile_count)
+{
+	__shared__ int2 s_lr[REFIT_TILE];
+	__shared__ float s_area[REFIT_TILE];
+	__shared__ uint16_t s_q[REFIT_TILE];
+	__shared__ int s_roots[REFIT_TILE / 2];
+	__shared__ uint32_t s_nroots;
+	const int lo = (int)blockIdx.x * REFIT_TILE;
+	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
+	tile_load(lo, hi, lr, range, area, climbers, s_lr, s_area, nullptr, s_roots, &s_nroots);
+	if (threadIdx.x < 64u) {
+		const uint32_t count = tile_bfs(lo, s_lr, s_area, nullptr, s_roots, s_nroots, nullptr, s_q, nullptr, nullptr, nullptr);
+		if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
+	}
+}
+
+__global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, int n, const int2 *lr, const uint2 *range, const BinNode *bin, const float *area,
+	const Climb *climbers, const unsigned long long *tile_parent, const uint32_t *tile_base, uint32_t node_offset, DevNode *nodes, DevNodeQ *qnodes,
+	uint32_t node_cap, DevSceneConsts *consts, uint32_t *depth_word)
+{
+	__shared__ int2 s_lr[REFIT_TILE];          //  8 KB
+	__shared__ float s_area[REFIT_TILE];       //  4 KB
+	__shared__ uint16_t s_start[REFIT_TILE];   //  2 KB: first sorted triangle of node lo + k's range, minus lo
+	__shared__ uint16_t s_base[REFIT_TILE];    //  2 KB: jobs whose range starts at lo + k, then their exclusive prefix sums
+	__shared__ uint16_t s_round[REFIT_TILE], s_spine[REFIT_TILE], s_map[REFIT_TILE];   // the jobs in breadth-first order; ...; number -> node
+	__shared__ uint8_t s_lvl[REFIT_TILE];
+	__shared__ int s_roots[REFIT_TILE / 2];    //  2 KB: the tile roots
+	__shared__ uint32_t s_nroots, s_count;
+	const int lo = (int)blockIdx.x * REFIT_TILE;
+	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
+	const int t = (int)threadIdx.x;
+	tile_load(lo, hi, lr, range, area, climbers, s_lr, s_area, s_start, s_roots, &s_nroots);
+	for (int k = t; k < REFIT_TILE; k += TILE_THREADS) s_base[k] = 0u;
+	__syncthreads();
+	if (t < 64) {
+		const uint32_t cnt = tile_bfs(lo, s_lr, s_area, s_start, s_roots, s_nroots, tile_parent, s_round, s_spine, s_lvl, reinterpret_cast<uint32_t *>(s_base));
+		// pre-order numbers: jobs that start further left (prefix sums over the per-start counters, 16 per lane) + jobs above
+		// with the same start
+		uint32_t sum = 0;
+		uint32_t v[16];
+#pragma unroll
+		for (int q = 0; q < 16; q++) { v[q] = s_base[16 * t + q]; sum += v[q]; }
+		uint32_t inc = sum;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (t >= o) inc += u; }
+		uint32_t run = inc - sum;
+#pragma unroll
+		for (int q = 0; q < 16; q++) { s_base[16 * t + q] = (uint16_t)run; run += v[q]; }
+		if (t == 0) s_count = cnt;
+	}
+	__syncthreads();
+	const uint32_t count = s_count;
+	const uint32_t base = node_offset + tile_base[blockIdx.x];
+#define TILE_LOCAL(k_) ((uint32_t)s_base[s_start[k_]] + (uint32_t)s_spine[k_])
+	// where each root hangs: child `slot` of node `pn`, made by the collapse of the levels above (tile_parent)
+	for (uint32_t r = (uint32_t)t; r < s_nroots; r += TILE_THREADS) {
+		const unsigned long long w = tile_parent[s_roots[r]];
+		const uint32_t pn = (uint32_t)(w >> 2), slot = (uint32_t)w & 3u;
+		if (pn < node_cap) nodes[pn].child[slot] = base + TILE_LOCAL(s_roots[r] - lo);
+	}
+	// number -> binary node (s_map), then the nodes themselves, dense: thread j makes wide nodes j, j + blockDim, ... of the tile
+	for (uint32_t j = (uint32_t)t; j < count; j += TILE_THREADS) { const uint32_t k = s_round[j]; s_map[TILE_LOCAL(k)] = (uint16_t)k; }
+	__syncthreads();
+	bool misfit = false;
+	uint32_t deepest = 0;
+	for (uint32_t j = (uint32_t)t; j < count; j += TILE_THREADS) {
+		const int bk = (int)s_map[j];
+		int ch4[4];
+		const int nc = tile_open(lo + bk, lo, s_lr, s_area, ch4);
+		DevNode nd;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			float mn[3], mx[3];
+			uint32_t ref;
+			if (k >= nc) {
+				mn[0] = mn[1] = mn[2] = 1.0f; mx[0] = mx[1] = mx[2] = -1.0f;      // inverted = never hit (rtk.c:1612-1620)
+				ref = RTK_REF_NONE;
+			} else if (ch4[k] < 0) {
+				tri_box(tris, (uint32_t)~ch4[k], mn, mx);                         // a leaf of one triangle (marked as such by k_emit_tris)
+				ref = RTK_REF_LEAF | (uint32_t)~ch4[k];
+			} else {
+				const float4 *src = reinterpret_cast<const float4 *>(bin + ch4[k]);
+				const float4 b0 = src[0], b1 = src[1];                            // mn.xyz cnt_flag | mx.xyz cost
+				mn[0] = b0.x; mn[1] = b0.y; mn[2] = b0.z; mx[0] = b1.x; mx[1] = b1.y; mx[2] = b1.z;
+				if (s_area[ch4[k] - lo] > 0.0f) ref = base + TILE_LOCAL(ch4[k] - lo);
+				else {
+					const uint2 lf = range[ch4[k]];                                // a subtree the SAH rule turned into one leaf
+					mark_leaf(tris, lf);
+					ref = RTK_REF_LEAF | lf.x;
+				}
+			}
+			nd.bx[0][k] = mn[0]; nd.bx[1][k] = mx[0];
+			nd.by[0][k] = mn[1]; nd.by[1][k] = mx[1];
+			nd.bz[0][k] = mn[2]; nd.bz[1][k] = mx[2];
+			nd.child[k] = ref;
+		}
+		child_order(nd, nd.order);
+		DevNodeQ q;
+		if (!quantize_node(nd, q)) misfit = true;
+		// (a tree with more nodes than the scene's arrays were sized for drops the writes beyond them; the host repeats)
+		if (base + j < node_cap) {
+			nodes[base + j] = nd;
+			qnodes[base + j] = q;
+		}
+		deepest = deepest > (uint32_t)s_lvl[bk] + 1u ? deepest : (uint32_t)s_lvl[bk] + 1u;      // (the scene's depth counts levels from 1)
+	}
+#undef TILE_LOCAL
+	if (misfit) atomicAdd(&consts->qnode_misfits, 1u);
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(deepest, o); deepest = deepest > u ? deepest : u; }
+	if ((t & 63) == 0 && deepest) atomicMax(depth_word, deepest);
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -1047,9 +1370,11 @@ bool is_device_ptr(const void *p)
 
 // Host memory -> device. A plain hipMemcpy (the runtime's own pinned staging) measured faster on the
 // GPU box than a hand-rolled double-buffered copy (19 vs 25 ms per 10M-triangle build, steady state).
-hipError_t upload_staged(void *dst, const void *src, size_t bytes)
+// (on the build's stream: a plain hipMemcpy from pageable memory is ordered with the NULL stream only, and may return before its
+// DMA has landed -- kernels on another stream would not wait for it. The caller's buffers outlive the build.)
+hipError_t upload_staged(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
-	return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+	return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
 }
 
 #define BUILD_CHECK(expr)                                                                               \
@@ -1174,6 +1499,8 @@ struct Workspace {
 	std::mutex mutex;
 	char *base = nullptr;
 	size_t cap = 0;
+	hipStream_t stream = nullptr;     // builds of this device run on a stream of their own (not the NULL stream, which would serialise
+	                                  // them with every blocking stream of the host), one at a time (the mutex: they share the workspace)
 };
 Workspace g_workspace[RTK_MAX_DEVICES];
 
@@ -1334,7 +1661,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	need += 2 * padded((size_t)n * 8) + padded((size_t)n * 12) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(16);   // lr, range, climbers, halves, arrive, root
 	need += padded((size_t)n * sizeof(BinNode));                                    // bin
 	need += padded((size_t)n * 16) + 2 * padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);   // collapse: dec, info, jobs, block sums, ring
-	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case)
+	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case; unused in tile mode)
+	need += 2 * padded(((size_t)n / REFIT_TILE + 4) * 4) + padded(16) + padded((size_t)n * 4);   // tile counts, tile bases, depth word, areas
 	Workspace &ws = g_workspace[device];
 	std::lock_guard<std::mutex> ws_lock(ws.mutex);
 	if (ws.cap < need) {
@@ -1349,6 +1677,15 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		} else ws.cap = want;
 	}
 	Arena ar = { ws.base, ws.cap, 0 };
+	if (!ws.stream && hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking) != hipSuccess) { ws.stream = nullptr; rtk_set_error("device build: hipStreamCreate failed"); return nullptr; }
+	const hipStream_t bs = ws.stream;
+	// a mesh that already lives in device memory was written by the caller's own work, possibly still in flight on the NULL
+	// stream or a blocking stream: that work is waited for here (a build stream of our own does not order itself behind it)
+	{
+		bool device_mesh = false;
+		for (size_t mi = 0; mi < desc->num_meshes; mi++) device_mesh = device_mesh || plans[mi].pos_on_device || plans[mi].idx_on_device;
+		if (device_mesh) BUILD_CHECK(hipStreamSynchronize(0));
+	}
 	stage("workspace");
 
 	// ---- 1 ingest ------------------------------------------------------------------
@@ -1356,8 +1693,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_bounds = ar.take<uint32_t>(16);
 	// centroid bounds: min words start at all ones, max words at zero (ordered-uint encoding): two fills, nothing the host
 	// waits for. The decode kernels below take them in passing.
-	BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, 0));
-	BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, 0));
+	BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, bs));
+	BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, bs));
 	bool bounds_pass_needed = false;          // some mesh came in as host-decoded records
 	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
 		const rtk_mesh *m = &desc->meshes[mi];
@@ -1374,7 +1711,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 				for (int c = 0; c < 9; c++) recs[t].p[c] = pos9[9 * t + c];
 				for (int c = 0; c < 3; c++) recs[t].vi[c] = vidx3[3 * t + c];
 			}
-			BUILD_CHECK(hipMemcpy(in_tris + base, recs.data(), recs.size() * sizeof(InTri), hipMemcpyHostToDevice));
+			BUILD_CHECK(hipMemcpyAsync(in_tris + base, recs.data(), recs.size() * sizeof(InTri), hipMemcpyHostToDevice, bs));
+			BUILD_CHECK(hipStreamSynchronize(bs));      // (recs goes out of scope)
 			bounds_pass_needed = true;
 			continue;
 		}
@@ -1382,18 +1720,18 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		const char *idx_ptr = pl.idx_src, *pos_ptr = pl.pos_src;
 		if (pl.ibytes) {
 			char *d = ar.take<char>(pl.ibytes);
-			BUILD_CHECK(upload_staged(d, pl.idx_src, pl.ibytes));
+			BUILD_CHECK(upload_staged(d, pl.idx_src, pl.ibytes, bs));
 			idx_ptr = d;
 		}
 		if (pl.pbytes) {
 			char *d = ar.take<char>(pl.pbytes);
-			BUILD_CHECK(upload_staged(d, pl.pos_src, pl.pbytes));
+			BUILD_CHECK(upload_staged(d, pl.pos_src, pl.pbytes, bs));
 			pos_ptr = d;
 		}
 		const unsigned iblocks = (unsigned)std::min<size_t>((nt + INGEST_BLOCK - 1) / INGEST_BLOCK, (size_t)num_cus);
-		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds);
-		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds);
-		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds);
+		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds, bs);
+		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds, bs);
+		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds, bs);
 		BUILD_CHECK(hipGetLastError());
 	}
 	stage("ingest");
@@ -1418,16 +1756,16 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	{
 		if (bounds_pass_needed) {
 			const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
-			hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, 0, in_tris, n, d_bounds);
+			hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, bs, in_tris, n, d_bounds);
 		}
-		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, n, d_bounds, keys_a, vals_a, 63u - key_bits);
+		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, n, d_bounds, keys_a, vals_a, 63u - key_bits);
 		BUILD_CHECK(hipGetLastError());
 	}
 	stage("morton");
 
 	// ---- 4 sort: no allocation, no host synchronisation ------------------------------------
-	const bool in_b = packed ? rtk_sort_words_async(keys_a, keys_b, n, 24u, 64u, sort_scratch, 0)
-	                         : rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, 0);
+	const bool in_b = packed ? rtk_sort_words_async(keys_a, keys_b, n, 24u, 64u, sort_scratch, bs)
+	                         : rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, bs);
 	const unsigned long long *keys = in_b ? keys_b : keys_a;      // packed: all different (the index is part of the word), in ascending order
 	const uint32_t *vals = packed ? nullptr : (in_b ? vals_b : vals_a);
 	BUILD_CHECK(hipGetLastError());
@@ -1462,8 +1800,8 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_slot_mesh = (uint32_t *)(tri_mem + o_smesh);
 	uint32_t *d_slot_tri = (uint32_t *)(tri_mem + o_stri);
 	{
-		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, 0) != hipSuccess) return fail("copy");
-		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, 0, in_tris, vals, keys, n, d_mesh_base,
+		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, bs) != hipSuccess) return fail("copy");
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, vals, keys, n, d_mesh_base,
 			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
 	}
@@ -1477,81 +1815,147 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_arrive = ar.take<uint32_t>(n);
 	int *d_root = ar.take<int>(4);
 	BinNode *d_bin = ar.take<BinNode>(n);
-	if (hipMemsetAsync(d_arrive, 0, (size_t)n * 4, 0) != hipSuccess) return fail("memset");
+	// tile mode (more than one refit tile): the subtrees inside a tile are collapsed by k_collapse_tile, only the nodes above
+	// them go through the level-by-level collapse. RTK_AMD_TILE_COLLAPSE=0: everything level by level (the round-2 path, A/B).
+	const uint32_t num_tiles = (n + REFIT_TILE - 1u) / REFIT_TILE;
+	// Measured on MI355X (profiles/r03_build_*): 3.30 against 3.53 ms at 10M triangles, 0.69 against 0.63 ms at 1M -- the fixed cost
+	// of the extra launches (count, scan, the small top collapse) is not earned back below a few million triangles, so tile
+	// mode starts at 2M. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read per build) moves that: 0 = whenever there are two tiles.
+	const char *tile_env = getenv("RTK_AMD_TILE_COLLAPSE_MIN");
+	const uint64_t tile_min = tile_env ? (uint64_t)atoll(tile_env) : (1ull << 21);
+	const bool tile_mode = num_tiles > 1u && (uint64_t)n >= tile_min;
+	uint32_t *d_tile_count = ar.take<uint32_t>(num_tiles + 1u), *d_tile_base = ar.take<uint32_t>(num_tiles + 1u);
+	uint32_t *d_depth_word = ar.take<uint32_t>(4);
+	float *d_area = tile_mode ? ar.take<float>(n) : (float *)nullptr;
+	if (hipMemsetAsync(d_arrive, 0, (size_t)n * 4, bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
-	hipLaunchKernelGGL(k_refit_tile, dim3((n + REFIT_TILE - 1u) / REFIT_TILE), dim3(REFIT_BLOCK), 0, 0, d_tris, (int)n, keys, d_lr, d_range,
-		d_bin, d_climbers, d_half, d_arrive, d_root, bp);
-	hipLaunchKernelGGL(k_refit_top, dim3((n + 255u) / 256u), dim3(256), 0, 0, d_tris, (int)n, keys, d_climbers, d_half, d_arrive, d_bin, d_lr, d_range,
-		d_root, bp);
+	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
+		d_bin, d_climbers, d_half, d_arrive, d_root, bp, d_area);
+	hipLaunchKernelGGL(k_refit_top, dim3((n + 255u) / 256u), dim3(256), 0, bs, d_tris, (int)n, keys, d_climbers, d_half, d_arrive, d_bin, d_lr, d_range,
+		d_root, bp, tile_mode);
+	if (tile_mode) {
+		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, bs, (int)n, d_lr, d_range, d_area, d_climbers, d_tile_count);
+		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, bs, d_tile_count, num_tiles, d_tile_base);
+	}
 	if (hipGetLastError() != hipSuccess) return fail("refit");
 	stage("refit");
 
-	// ---- 8 collapse: one launch for the small levels at the top, two per big level, one for the tail ---------
+	// ---- 8 collapse: level by level for the nodes above the tiles (all nodes without tile mode), then the tiles ---------
 	CollapseBufs cb;
 	cb.jobs = ar.take<int>(n);
 	cb.dec = ar.take<int4>(n);
 	cb.info = ar.take<uint32_t>(n);
 	cb.sums = ar.take<uint32_t>(collapse_blocks);
 	LevelState *d_ring = ar.take<LevelState>(COLLAPSE_RING);
-	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
-	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
+	DevNode *d_nodes_tmp = tile_mode ? (DevNode *)nullptr : ar.take<DevNode>(n);
+	if (!tile_mode && !d_nodes_tmp) return fail("workspace too small (internal error)");
+	// pass 2's hand-over words are dead once it has run: the same array tells k_collapse_tile where each tile root hangs
+	unsigned long long *d_tile_parent = tile_mode ? d_half : (unsigned long long *)nullptr;
 	LevelState h_state = {};
 	// The node arrays of the scene, [DevNode x node_cap | DevNodeQ x node_cap], are allocated now -- the GPU is still busy
 	// with the refit -- at the size 4-wide trees over n triangles usually have (0.47 n on the benchmark scenes), and the
 	// collapse writes its nodes straight into them. A tree with more nodes than that drops the writes beyond the capacity
-	// (the kernels check) and is collapsed once more into the workspace, which holds n nodes.
+	// (the kernels check) and is collapsed once more: into an exact allocation (tile mode) or into the workspace.
 	void *node_mem = nullptr;
 	// (RTK_AMD_NODE_ESTIMATE_DIV: n / div + 16 instead, to drive the repeat path from tests)
 	const int est_div = getenv("RTK_AMD_NODE_ESTIMATE_DIV") ? atoi(getenv("RTK_AMD_NODE_ESTIMATE_DIV")) : 0;
 	size_t node_cap = est_div > 0 ? (size_t)n / (size_t)est_div + 16 : (size_t)n / 2 + 4096;
 	if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) { (void)hipGetLastError(); node_mem = nullptr; node_cap = 0; }
 	else ds->allocs.push_back(node_mem);      // owned by the scene from here on (error paths free it with the scene)
-	auto run_collapse = [&](DevNode *target, uint32_t cap) -> bool {
-		const unsigned big_blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
-		// levels with more than COLLAPSE_SMALL jobs in a balanced 4-wide tree over n triangles, plus slack; a tree that is
+	auto run_collapse = [&](DevNode *target, uint32_t cap, uint64_t jobs_hint) -> bool {
+		const unsigned big_blocks = (unsigned)std::min<uint64_t>((jobs_hint + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK, (uint64_t)num_cus * 16);
+		// levels with more than COLLAPSE_SMALL jobs in a balanced 4-wide tree over jobs_hint leaves, plus slack; a tree that is
 		// deeper than that takes further rounds
 		unsigned big_levels = 2;
-		for (uint64_t c = COLLAPSE_SMALL_JOBS; c < n; c *= 4) big_levels++;
+		for (uint64_t c = COLLAPSE_SMALL_JOBS; c < jobs_hint; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, d_tile_parent);
 			for (unsigned k = 0; k < big_levels; k++) {
 				// number the level of ring entry `step` (-> entry step + 1: the next level, not opened yet), then open that
-				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, target, cap);
+				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, target, cap);
 				step++;
-				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, 0, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, target, cap);
+				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, target, cap, d_tile_parent);
 			}
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, 0, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, d_tile_parent);
 			if (hipGetLastError() != hipSuccess ||
-				hipMemcpy(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost) != hipSuccess) return false;
+				hipMemcpyAsync(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost, bs) != hipSuccess ||
+				hipStreamSynchronize(bs) != hipSuccess) return false;
 			if (h_state.count == 0) return true;
 			if (round > 4096) return false;
 			big_levels = 4;
 		}
 	};
-	bool in_place = node_mem != nullptr;
-	if (!run_collapse(in_place ? (DevNode *)node_mem : d_nodes_tmp, in_place ? (uint32_t)node_cap : n)) return fail("collapse");
-	if (in_place && h_state.total_nodes > node_cap) {
-		// the estimate was too small: once more, into the workspace; then an exact allocation
-		ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr;      // it was the last one pushed
-		in_place = false;
-		if (!run_collapse(d_nodes_tmp, n)) return fail("collapse");
-	}
-	const uint32_t total_nodes = h_state.total_nodes, depth = h_state.depth;
-	stage("collapse");
-
-	if (!node_mem) {
-		node_cap = total_nodes ? total_nodes : 1;
-		if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
-		ds->allocs.push_back(node_mem);
+	uint32_t total_nodes = 0, depth = 0;
+	if (tile_mode) {
+		if (rtk_scene_consts(ds, bs) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+		DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
+		uint32_t h_tail[2] = { 0u, 0u };      // { wide nodes of all tiles, deepest level }
+		for (int attempt = 0;; attempt++) {
+			if (!node_mem) {
+				// (second attempt, or the estimate could not be allocated: the exact size is known by now or will be after one dry round)
+				if (attempt == 0) { node_cap = 0; }
+			}
+			DevNode *d_nodes_ = (DevNode *)node_mem;
+			// the nodes above the tiles: ~15 tile roots per tile hang below them
+			if (!run_collapse(d_nodes_, (uint32_t)node_cap, (uint64_t)num_tiles * 16u)) return fail("collapse");
+			const uint32_t top_nodes = h_state.total_nodes;
+			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, bs, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_climbers, d_tile_parent,
+				d_tile_base, top_nodes, d_nodes_, (DevNodeQ *)(d_nodes_ + node_cap), (uint32_t)node_cap, consts, d_depth_word);
+			if (hipGetLastError() != hipSuccess ||
+				hipMemcpyAsync(&h_tail[0], d_tile_base + num_tiles, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
+				hipMemcpyAsync(&h_tail[1], d_depth_word, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
+				hipStreamSynchronize(bs) != hipSuccess) return fail("tile collapse");
+			if (timing) {
+				std::vector<uint32_t> hc(num_tiles + 1), hb(num_tiles + 1);
+				(void)hipMemcpy(hc.data(), d_tile_count, (num_tiles) * 4, hipMemcpyDeviceToHost);
+				(void)hipMemcpy(hb.data(), d_tile_base, (num_tiles + 1) * 4, hipMemcpyDeviceToHost);
+				fprintf(stderr, "rtk_amd build: top %u tiles %u tail %u depth %u cap %zu counts %u %u %u bases %u %u %u\n", top_nodes, num_tiles, h_tail[0], h_tail[1], node_cap,
+					hc[0], hc[1], hc[num_tiles - 1], hb[0], hb[1], hb[num_tiles]);
+			}
+			total_nodes = top_nodes + h_tail[0];
+			depth = h_tail[1] > h_state.depth ? h_tail[1] : h_state.depth;
+			if (total_nodes <= node_cap) {
+				// order words and compressed copies of the nodes above the tiles (their child words are complete only now), scene constants
+				ds->view.nodes = d_nodes_;
+				ds->view.num_nodes = total_nodes;
+				if (rtk_quantize_nodes(ds, bs, nullptr, (DevNodeQ *)(d_nodes_ + node_cap), 0.0f, top_nodes ? top_nodes : 1u, true) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+				break;
+			}
+			if (attempt > 0) return fail("collapse (internal error: node count changed between two runs)");
+			// the estimate was too small: an exact allocation, and once more (both collapses are deterministic)
+			if (node_mem) { ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr; }     // it was the last one pushed
+			node_cap = total_nodes;
+			if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
+			ds->allocs.push_back(node_mem);
+			if (hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
+		}
+		stage("collapse");
+	} else {
+		bool in_place = node_mem != nullptr;
+		if (!run_collapse(in_place ? (DevNode *)node_mem : d_nodes_tmp, in_place ? (uint32_t)node_cap : n, n)) return fail("collapse");
+		if (in_place && h_state.total_nodes > node_cap) {
+			// the estimate was too small: once more, into the workspace; then an exact allocation
+			ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr;      // it was the last one pushed
+			in_place = false;
+			if (!run_collapse(d_nodes_tmp, n, n)) return fail("collapse");
+		}
+		total_nodes = h_state.total_nodes;
+		depth = h_state.depth;
+		stage("collapse");
+		if (!node_mem) {
+			node_cap = total_nodes ? total_nodes : 1;
+			if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
+			ds->allocs.push_back(node_mem);
+		}
+		DevNode *d_nodes_ = (DevNode *)node_mem;
+		ds->view.nodes = d_nodes_;
+		ds->view.num_nodes = total_nodes;
+		// compressed nodes beside the exact ones (and, if the collapse had to go through the workspace, the exact ones out of it)
+		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
 	}
 	ds->total_bytes += node_cap * (sizeof(DevNode) + sizeof(DevNodeQ));
-	DevNode *d_nodes = (DevNode *)node_mem;
-	ds->view.nodes = d_nodes;
-	ds->view.num_nodes = total_nodes;
-	// compressed nodes beside the exact ones (and, if the collapse had to go through the workspace, the exact ones out of it)
-	if (rtk_quantize_nodes(ds, 0, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
-	if (hipStreamSynchronize(0) != hipSuccess) return fail("sync");   // the workspace is handed back below
+	if (hipStreamSynchronize(bs) != hipSuccess) return fail("sync");   // the workspace is handed back below
 	rtk_quantize_finish(ds);
 
 	ds->view.tris = d_tris;

@@ -162,7 +162,11 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
 // Also writes every node's child order words and the scene constants (DevSceneConsts, allocated here). bound_hint: a bound of
 // |plane| over all nodes the caller already knows (uploads: computed on the host, boxes of a blob need not nest); the root's
 // own planes are always taken in.
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr, float bound_hint = 0.0f);
+// only_first: finish just the first so many nodes (the device build's tile collapse has finished the others itself);
+// keep_consts: the constants block is already set up (rtk_scene_consts) and holds counts that must survive.
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr, float bound_hint = 0.0f,
+	uint32_t only_first = 0xffffffffu, bool keep_consts = false);
+int rtk_scene_consts(rtk_dev_scene *ds, hipStream_t stream);
 void rtk_quantize_finish(rtk_dev_scene *ds);   // after that stream has been synchronised
 
 // -- radix sort shared with the builder (rtk_build.hip) --

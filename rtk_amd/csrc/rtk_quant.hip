@@ -1,48 +1,11 @@
 // rtk_quant.hip -- DevNode (128 B, exact child boxes) -> DevNodeQ (64 B, 8-bit planes), one thread per node.
 // Used after a device build and after a blob upload; see rtk_dev.h for the format and why it exists.
 #include "rtk_dev.h"
+#include "rtk_node_finish.h"
 
 #include <math.h>
 
 namespace {
-
-// largest power of two s.t. 254 steps still cover `extent` is too coarse by up to 2x; this picks the smallest
-// power of two with 254 * s >= extent (one level is kept in reserve for the round-up of the high planes)
-__device__ __forceinline__ float grid_step(float extent)
-{
-	if (!(extent > 0.0f)) return 1.17549435e-38f;            // flat on this axis: every plane sits at q = 0
-	int e;
-	(void)frexpf(extent, &e);                                // extent = m * 2^e, m in [0.5, 1)
-	float s = ldexpf(1.0f, e - 8);                           // 256 * s = 2^e > extent
-	if (254.0f * s < extent) s *= 2.0f;
-	return s;
-}
-
-// Front-to-back order of the children per direction octant (DevNode::order): by the centre of the child box along the
-// octant's diagonal, empty slots last, ties by slot number.
-__device__ __forceinline__ void child_order(const DevNode &nd, uint32_t order[4])
-{
-	order[0] = order[1] = order[2] = order[3] = 0u;
-	for (uint32_t o = 0; o < 8u; o++) {
-		float key[4];
-		for (int k = 0; k < 4; k++) {
-			const float cx = nd.bx[0][k] + nd.bx[1][k], cy = nd.by[0][k] + nd.by[1][k], cz = nd.bz[0][k] + nd.bz[1][k];
-			float s = ((o & 1u) ? -cx : cx) + ((o & 2u) ? -cy : cy) + ((o & 4u) ? -cz : cz);
-			if (!(s == s)) s = INFINITY;                           // NaN boxes sort behind everything real
-			key[k] = nd.child[k] == RTK_REF_NONE ? INFINITY : s;
-		}
-		// rank of slot k = how many slots come before it
-		uint32_t word = 0u, pair = 0u, bit = 0u;
-		for (int i = 0; i < 4; i++) {
-			uint32_t rank = 0;
-			for (int j = 0; j < 4; j++) if (j != i && (key[j] < key[i] || (key[j] == key[i] && j < i))) rank++;
-			word |= (uint32_t)i << (2u * rank);
-			for (int j = i + 1; j < 4; j++, bit++) if (key[j] < key[i]) pair |= 1u << bit;   // the second of the pair comes first
-		}
-		word |= pair << RTK_ORDER_PAIR_SHIFT;
-		order[o >> 1] |= word << (16u * (o & 1u));
-	}
-}
 
 // copy_to: also store the exact node there (the device build hands its workspace copy over in the same pass)
 __global__ void k_quantize(DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *copy_to, DevSceneConsts *consts, float bound_hint)
@@ -64,44 +27,7 @@ __global__ void k_quantize(DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *c
 		consts->bound_abs = b;
 	}
 	DevNodeQ q;
-	bool misfit = false;
-	const float *lo[3] = { nd.bx[0], nd.by[0], nd.bz[0] }, *hi[3] = { nd.bx[1], nd.by[1], nd.bz[1] };
-#pragma unroll
-	for (int a = 0; a < 3; a++) {
-		float mn = INFINITY, mx = -INFINITY;
-		for (int k = 0; k < 4; k++) if (nd.child[k] != RTK_REF_NONE) { mn = fminf(mn, lo[a][k]); mx = fmaxf(mx, hi[a][k]); }
-		if (!(mn <= mx)) { mn = 0.0f; mx = 0.0f; }             // a node without children (empty scene)
-		float s = grid_step(mx - mn);
-		uint32_t wl = 0, wh = 0;
-		for (int attempt = 0; attempt < 4; attempt++) {
-			bool fits = true;
-			wl = wh = 0;
-			for (int k = 0; k < 4; k++) {
-				uint32_t ql = 255u, qh = 0u;                       // empty slot: inverted, can never be entered
-				if (nd.child[k] != RTK_REF_NONE) {
-					// floor / ceil in float, then made safe in double: org + q * s is exact there
-					float fl = floorf((lo[a][k] - mn) / s), fh = ceilf((hi[a][k] - mn) / s);
-					fl = fminf(fmaxf(fl, 0.0f), 255.0f);
-					fh = fminf(fmaxf(fh, 0.0f), 300.0f);
-					ql = (uint32_t)fl; qh = (uint32_t)fh;
-					while (ql > 0u && (double)mn + (double)ql * (double)s > (double)lo[a][k]) ql--;
-					while (qh < 300u && (double)mn + (double)qh * (double)s < (double)hi[a][k]) qh++;
-					if (qh > 255u) fits = false;
-				}
-				wl |= (ql & 255u) << (8 * k);
-				wh |= (qh & 255u) << (8 * k);
-			}
-			if (fits) break;
-			// (an extent that is not finite in float -- planes beyond +-1.7e38 or inf -- never fits: frexpf(inf) gives a tiny step)
-			if (attempt == 3) misfit = true;
-			s *= 2.0f;
-		}
-		q.org[a] = mn;
-		q.scale[a] = s;
-		q.q[a][0] = wl;
-		q.q[a][1] = wh;
-	}
-	for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
+	const bool misfit = !quantize_node(nd, q);
 	out[i] = q;
 	// a compressed box that does not contain its exact box would cull real hits: the host then keeps the scene on its exact nodes
 	if (misfit) atomicAdd(&consts->qnode_misfits, 1u);
@@ -109,22 +35,29 @@ __global__ void k_quantize(DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *c
 
 } // namespace
 
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst, float bound_hint)
+// The scene's constants word block, allocated on first use and cleared on `stream`.
+int rtk_scene_consts(rtk_dev_scene *ds, hipStream_t stream)
 {
-	const uint32_t n = ds->view.num_nodes;
-	void *p = dst;
 	if (!ds->view.consts) {
 		void *c = nullptr;
 		RTK_HIP_CHECK(hipMalloc(&c, sizeof(DevSceneConsts)), RTK_AMD_ERR_OOM);
 		ds->allocs.push_back(c);
 		ds->view.consts = (const DevSceneConsts *)c;
 	}
+	RTK_HIP_CHECK(hipMemsetAsync(const_cast<DevSceneConsts *>(ds->view.consts), 0, sizeof(DevSceneConsts), stream), RTK_AMD_ERR_HIP);   // (bound_abs 0 = no nodes; kernels read it as max(bound, 1))
+	return RTK_AMD_OK;
+}
+
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst, float bound_hint, uint32_t only_first, bool keep_consts)
+{
+	const uint32_t n = ds->view.num_nodes < only_first ? ds->view.num_nodes : only_first;
+	void *p = dst;
+	if (!keep_consts || !ds->view.consts) { const int rc = rtk_scene_consts(ds, stream); if (rc != RTK_AMD_OK) return rc; }
 	DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
-	RTK_HIP_CHECK(hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), stream), RTK_AMD_ERR_HIP);   // (bound_abs 0 = no nodes; kernels read it as max(bound, 1))
 	if (!p) {
-		RTK_HIP_CHECK(hipMalloc(&p, (size_t)(n ? n : 1) * sizeof(DevNodeQ)), RTK_AMD_ERR_OOM);
+		RTK_HIP_CHECK(hipMalloc(&p, (size_t)(ds->view.num_nodes ? ds->view.num_nodes : 1) * sizeof(DevNodeQ)), RTK_AMD_ERR_OOM);
 		ds->allocs.push_back(p);
-		ds->total_bytes += (size_t)n * sizeof(DevNodeQ);
+		ds->total_bytes += (size_t)ds->view.num_nodes * sizeof(DevNodeQ);
 	}
 	// src: the nodes still sit in a workspace; ds->view.nodes (allocated, not yet filled) receives them in the same pass
 	if (n) hipLaunchKernelGGL(k_quantize, dim3((n + 255u) / 256u), dim3(256), 0, stream, const_cast<DevNode *>(src ? src : ds->view.nodes), n, (DevNodeQ *)p,

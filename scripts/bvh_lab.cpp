@@ -27,7 +27,7 @@ static uint64_t spread21(uint32_t v) {
 }
 
 // binary tree: nodes 0..n-2 inner; child >=0 inner, <0 leaf ~sorted_index
-struct Bin { int l, r; Box b; uint32_t cnt; float cost; bool leaf; };
+struct Bin { int l, r; Box b; uint32_t cnt; float cost; bool leaf; int lo, hi; };
 static std::vector<Bin> bin; static int root;
 static std::vector<uint32_t> order;  // sorted index -> prim
 static std::vector<Box> pbox;        // per sorted index
@@ -75,7 +75,7 @@ static int lbvh_rec(int lo, int hi) {   // returns child ref
 	}
 	int id = (int)bin.size(); bin.push_back(Bin());
 	int l = lbvh_rec(lo, split), r = lbvh_rec(split + 1, hi);
-	bin[id].l = l; bin[id].r = r;
+	bin[id].l = l; bin[id].r = r; bin[id].lo = lo; bin[id].hi = hi;
 	return id;
 }
 
@@ -237,7 +237,9 @@ static void gather_prims(int ref, std::vector<uint32_t> &out) { if (ref < 0) { o
 static int make_leaf(int ref) { Leaf l; gather_prims(ref, l.prims); leaves.push_back(l); return ~(int)(leaves.size() - 1); }
 
 static Box ref_box(int ref) { return ref < 0 ? pbox[~ref] : bin[ref].b; }
+static int FORCE_TILE = 0;   // > 0: a binary node whose sorted range lies inside one tile of this many triangles is never opened INSIDE a wide node above it: it becomes a wide node of its own (the device build's tile-local collapse)
 static bool ref_open(int ref) { return ref >= 0 && !bin[ref].leaf; }
+static bool in_tile(int ref) { return FORCE_TILE > 0 && bin[ref].lo / FORCE_TILE == bin[ref].hi / FORCE_TILE; }
 
 static void collapse() {
 	wide.clear(); leaves.clear();
@@ -252,7 +254,7 @@ static void collapse() {
 			if (COLLAPSE_MODE == 0) {
 				for (int round = 0; round < WIDTH - 2; round++) {
 					int best = -1; float ba = 0;
-					for (int k = 0; k < nc; k++) if (ref_open(c[k])) {
+					for (int k = 0; k < nc; k++) if (ref_open(c[k]) && !(in_tile(c[k]) && !in_tile(b))) {
 						float a = harea(bin[c[k]].b);
 						if (COLLAPSE_CRIT == 1) a *= (float)bin[c[k]].cnt;                                   // area x triangles below
 						else if (COLLAPSE_CRIT == 2) a = a - 0.5f * (harea(ref_box(bin[c[k]].l)) + harea(ref_box(bin[c[k]].r)));   // what opening saves
@@ -506,6 +508,7 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-w")) WIDTH = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-om")) ORDERMODE = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-bins")) SAH_BINS = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-ft")) FORCE_TILE = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-pk")) PK_LANES = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-pe")) PK_ENTRY_DEPTH = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-po")) PK_ORDER = atoi(argv[++i]);

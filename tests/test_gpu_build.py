@@ -530,3 +530,34 @@ print("OK", int(gm.sum()), c["content_hash"])
         outs.append(r.stdout.split())
     assert int(outs[0][1]) > 500 and outs[0][1] == outs[1][1] == outs[2][1]        # same hits either way
     assert outs[0][2] == outs[2][2]                                                # and the very same tree after the repeat
+
+
+@pytest.mark.parametrize("n", [1025, 10_000, 300_000])
+def test_tile_local_collapse_at_small_sizes(api, oracle, n, monkeypatch):
+    """The tile-local collapse (k_count_tile / k_collapse_tile: subtrees inside a 1024-triangle refit tile are turned into
+    4-wide nodes by the tile's own workgroup, numbered in pre-order behind the nodes above the tiles) is the default from 2M
+    triangles on; RTK_AMD_TILE_COLLAPSE_MIN=0 forces it here. Structure validates (every child after its parent, exact
+    boxes, every triangle once), two builds are byte-identical, the level-by-level build of the same input holds the same
+    triangles, and tracing is bit-identical to the oracle on the exported blob."""
+    tris = synth.triangle_soup(n, 0.05, seed=70)
+    monkeypatch.setenv("RTK_AMD_TILE_COLLAPSE_MIN", "0")
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    ok, c = ds.validate()
+    assert ok and c["triangles_checked"] == n and c["loose_boxes"] == 0, c
+    ds_b = api.DeviceScene.build([dict(positions=tris)])
+    assert ds_b.validate()[1]["content_hash"] == c["content_hash"]
+    assert ds_b.export_blob().tobytes() == ds.export_blob().tobytes()
+    monkeypatch.setenv("RTK_AMD_TILE_COLLAPSE_MIN", str(1 << 40))
+    ds_level = api.DeviceScene.build([dict(positions=tris)])
+    ok2, c2 = ds_level.validate()
+    assert ok2 and c2["content_hash"] != c["content_hash"]          # another (valid) tree: tile roots are never opened from above
+    rays = synth.rays_config1(16384)
+    blob = _as_blob(oracle, ds.export_blob())
+    _same_as_oracle(oracle, blob, ds, rays, "tile-local collapse vs oracle on exported blob")
+    rec_img = ds.trace(rays, opts=api.make_opts(image=(128, 128)), full=False)
+    assert rec_img.tobytes() == ds.trace(rays, full=False).tobytes()
+    # the two trees agree on every hit but near-ties (ids exact, t to 1e-5 through compare_hits' tolerance on another BVH)
+    h1, m1, _ = ds.trace(rays)
+    h2, m2, _ = ds_level.trace(rays)
+    compare_hits(m1, h1["mesh_index"], h1["triangle_index"], h1["t"], h1["u"], h1["v"],
+                 m2, h2["mesh_index"], h2["triangle_index"], h2["t"], h2["u"], h2["v"], "tile collapse vs level collapse")
