@@ -9,8 +9,11 @@ prof() { wl=$1; kern=$2; RTK_PROFILE_KERNEL="$kern" bash scripts/profile_workloa
 prof coherent "rtk_packet_hot"
 prof incoherent "rtk_trace_kernel<0, false, false, true>"
 prof shadow "rtk_trace_kernel<1, false, false, true>"
+for n in 1000000 10000000; do bash scripts/profile_build.sh $n > gpurun_out/r03_build_profile_$n.log 2>&1; cp gpurun_out/build_kernel_stats_$n.csv gpurun_out/r03_build_kernel_stats_$((n / 1000000))M.csv; grep -E "k_|rc=" gpurun_out/r03_build_profile_$n.log | head -12; done
+gcc -O2 -o examples/host_latency examples/host_latency.c -Iinclude -Lrtk_amd -lrtk_amd -lpthread -Wl,-rpath,$PWD/rtk_amd 2>/dev/null && timeout -k 10 200 ./examples/host_latency > gpurun_out/r03_c_host_latency.log 2>&1; echo "c host rc=$?"; tail -6 gpurun_out/r03_c_host_latency.log
+timeout -k 10 400 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err; echo "bench default rc=$?"
 for wl in coherent incoherent shadow; do
-  timeout -k 10 400 python bench.py --steps 20 --warmup 5 --workload $wl > gpurun_out/r03_bench_$wl.json 2> gpurun_out/r03_bench_$wl.err; echo "bench $wl rc=$?"
+  timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-other-workloads --workload $wl > gpurun_out/r03_bench_$wl.json 2> gpurun_out/r03_bench_$wl.err; echo "bench $wl rc=$?"
   python3 -c "
 import json
 d=json.loads(open('gpurun_out/r03_bench_$wl.json').read().strip().splitlines()[-1])
