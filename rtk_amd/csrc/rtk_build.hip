@@ -1816,11 +1816,12 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	int *d_root = ar.take<int>(4);
 	BinNode *d_bin = ar.take<BinNode>(n);
 	// tile mode (more than one refit tile): the subtrees inside a tile are collapsed by k_collapse_tile, only the nodes above
-	// them go through the level-by-level collapse. RTK_AMD_TILE_COLLAPSE=0: everything level by level (the round-2 path, A/B).
+	// them go through the level-by-level collapse.
 	const uint32_t num_tiles = (n + REFIT_TILE - 1u) / REFIT_TILE;
 	// Measured on MI355X (profiles/r03_build_*): 3.30 against 3.53 ms at 10M triangles, 0.69 against 0.63 ms at 1M -- the fixed cost
 	// of the extra launches (count, scan, the small top collapse) is not earned back below a few million triangles, so tile
-	// mode starts at 2M. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read per build) moves that: 0 = whenever there are two tiles.
+	// mode starts at 2M. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read per build) moves that: 0 = whenever there are two tiles,
+	// a huge value = never (everything level by level, the round-2 path: A/B).
 	const char *tile_env = getenv("RTK_AMD_TILE_COLLAPSE_MIN");
 	const uint64_t tile_min = tile_env ? (uint64_t)atoll(tile_env) : (1ull << 21);
 	const bool tile_mode = num_tiles > 1u && (uint64_t)n >= tile_min;
