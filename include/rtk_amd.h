@@ -86,6 +86,7 @@ typedef struct rtk_trace_opts {
 #define RTK_TRACE_NO_PACKET 2u   /* image-shaped batch, but use the per-lane kernel (A/B only) */
 #define RTK_TRACE_EXACT_NODES 8u  /* per-lane kernels: read the 128 B exact nodes instead of the 64 B compressed ones (A/B only) */
 #define RTK_TRACE_NO_ASM 16u      /* image-shaped batch: C++ packet kernel only, not the hand-written one (A/B only) */
+#define RTK_TRACE_POOL 32u        /* large plain batch: the LDS ray-pool kernel instead of rays bound to lanes (experimental: slower on MI355X) */
 #define RTK_TRACE_SORT_RAYS 4u   /* reorder the batch by (origin cell, direction octant) before tracing; hits
                                     still land in input order. Pays off for large incoherent batches. */
 

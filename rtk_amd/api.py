@@ -21,6 +21,8 @@ RTK_TRACE_STATIC = 1
 RTK_TRACE_NO_PACKET = 2
 RTK_TRACE_SORT_RAYS = 4
 RTK_TRACE_EXACT_NODES = 8
+RTK_TRACE_NO_ASM = 16
+RTK_TRACE_POOL = 32
 
 
 class RtkError(RuntimeError):
@@ -196,12 +198,17 @@ def to_device(a):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
 
 
-def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, exact_nodes=False):
+def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, exact_nodes=False,
+              no_asm=False, pool=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
     if exact_nodes:
         o.flags |= RTK_TRACE_EXACT_NODES
+    if no_asm:
+        o.flags |= RTK_TRACE_NO_ASM
+    if pool:
+        o.flags |= RTK_TRACE_POOL
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

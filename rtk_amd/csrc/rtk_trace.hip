@@ -24,81 +24,7 @@
 
 #include <mutex>
 
-__device__ __forceinline__ float4 ld_f4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
-typedef float f32x4_ __attribute__((ext_vector_type(4)));
-// rays are read once and hit records written once: streamed past the caches ("nt") so that they do not push the BVH out of the L2
-__device__ __forceinline__ float4 ld_f4_stream(const char *p)
-{
-	const f32x4_ v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ *>(p));
-	return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st_f4_stream(void *p, float x, float y, float z, float w)
-{
-	f32x4_ v;
-	v.x = x; v.y = y; v.z = z; v.w = w;
-	__builtin_nontemporal_store(v, reinterpret_cast<f32x4_ *>(p));
-}
-__device__ __forceinline__ uint4 ld_u4(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// All seven 16-B pieces of a node are requested back to back and waited for once. Left to
-// itself hipcc serialises them (load, wait, reuse the registers, load ...) to save VGPRs,
-// which turns one memory round trip per node into four. SGPR base + 32-bit VGPR offsets.
-__device__ __forceinline__ void load_node(const char *base, uint32_t a_nx, uint32_t a_fx, uint32_t a_ny, uint32_t a_fy,
-	uint32_t a_nz, uint32_t a_fz, uint32_t a_node, f32x4 &nx, f32x4 &fx, f32x4 &ny, f32x4 &fy, f32x4 &nz, f32x4 &fz, u32x4 &ch)
-{
-	asm volatile(
-		"global_load_dwordx4 %0, %7, %14\n\t"
-		"global_load_dwordx4 %1, %8, %14\n\t"
-		"global_load_dwordx4 %2, %9, %14\n\t"
-		"global_load_dwordx4 %3, %10, %14\n\t"
-		"global_load_dwordx4 %4, %11, %14\n\t"
-		"global_load_dwordx4 %5, %12, %14\n\t"
-		"global_load_dwordx4 %6, %13, %14 offset:96\n\t"
-		"s_waitcnt vmcnt(0)"
-		: "=&v"(nx), "=&v"(fx), "=&v"(ny), "=&v"(fy), "=&v"(nz), "=&v"(fz), "=&v"(ch)
-		: "v"(a_nx), "v"(a_fx), "v"(a_ny), "v"(a_fy), "v"(a_nz), "v"(a_fz), "v"(a_node), "s"(base)
-		: "memory");
-}
-
-__device__ __forceinline__ void load_tri(const char *base, uint32_t a_tri, f32x4 &A, f32x4 &B, f32x4 &C)
-{
-	asm volatile(
-		"global_load_dwordx4 %0, %3, %4\n\t"
-		"global_load_dwordx4 %1, %3, %4 offset:16\n\t"
-		"global_load_dwordx4 %2, %3, %4 offset:32\n\t"
-		"s_waitcnt vmcnt(0)"
-		: "=&v"(A), "=&v"(B), "=&v"(C)
-		: "v"(a_tri), "s"(base)
-		: "memory");
-}
-
-// 64 B compressed node (DevNodeQ): four 16-B pieces, one wait.
-__device__ __forceinline__ void load_qnode(const char *base, uint32_t a_node, f32x4 &l0, u32x4 &l1, u32x4 &l2, u32x4 &l3)
-{
-	asm volatile(
-		"global_load_dwordx4 %0, %4, %5\n\t"
-		"global_load_dwordx4 %1, %4, %5 offset:16\n\t"
-		"global_load_dwordx4 %2, %4, %5 offset:32\n\t"
-		"global_load_dwordx4 %3, %4, %5 offset:48\n\t"
-		"s_waitcnt vmcnt(0)"
-		: "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-		: "v"(a_node), "s"(base)
-		: "memory");
-}
-
-__device__ __forceinline__ float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyteK
-
-__device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb)
-{
-	const bool s = kb < ka;
-	const float k0 = s ? kb : ka, k1 = s ? ka : kb;
-	const uint32_t r0 = s ? rb : ra, r1 = s ? ra : rb;
-	ka = k0; kb = k1; ra = r0; rb = r1;
-}
+#include "rtk_trace_lane.h"
 
 // A push that does not fit the stack (LDS entries + the global spill area sized from the tree depth) is
 // dropped WITHOUT advancing sp and flagged; it cannot happen for a tree (at most three pushes per level,
@@ -159,6 +85,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 	const char *const qnodes = reinterpret_cast<const char *>(p.sc.qnodes);
 	const char *const tris = reinterpret_cast<const char *>(p.sc.tris);
 
+	// (a list whose length an earlier kernel of the launch wrote: the pool kernel's left-over rays)
+	if (p.n_indirect) p.n = *p.n_indirect;
 	// wave-uniform ray range owned by this wave
 	unsigned long long w_next, w_end;
 	bool pool_empty;
@@ -889,10 +817,22 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu);
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
+	// The ray-pool kernel (rtk_trace_pool.hip: one workgroup per CU with its rays in LDS, every wave trip on 64 rays that want the
+	// same kind of step; the rays it leaves over -- non-finite or zero components -- follow in rtk_trace_kernel) is an OPTION, not
+	// the default: on MI355X it reaches 83 % / 99 % lane use in node / triangle steps but half the rate of rtk_trace_kernel
+	// (1.42 against 2.86 Grays/s on incoherent rays: its trips are bound by their chain of LDS round trips at the 16 waves per
+	// CU the pool leaves room for). RTK_AMD_POOL=1 or RTK_TRACE_POOL ask for it on plain closest-hit / any-hit
+	// batches with compressed nodes.
+	static const int pool_default = getenv("RTK_AMD_POOL") ? atoi(getenv("RTK_AMD_POOL")) : 0;
+	static const size_t pool_min_rays = getenv("RTK_AMD_POOL_MIN_RAYS") ? (size_t)atoll(getenv("RTK_AMD_POOL_MIN_RAYS")) : (size_t)1 << 18;
+	const bool pool_asked = pool_default != 0 || (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_POOL));
+	const bool pool = pool_asked && !packet && !collect && !counted && !filtered && qn && p.dynamic && n >= pool_min_rays && n < 0xffffffc0ull &&
+		ds->stack_entries < 0xffffu && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_STATIC));
 
 	const size_t blocks_needed = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
 	size_t blocks = (p.dynamic || packet) ? (size_t)ds->num_cus * blocks_per_cu : blocks_needed;
 	if (blocks > blocks_needed) blocks = blocks_needed;
+	const size_t pool_blocks = (size_t)ds->num_cus;
 	if (blocks > 0x7fffffffu) { rtk_set_error("rtk_dev_trace: batch too large for one launch"); return RTK_AMD_ERR_BAD_ARG; }
 
 	// From here on the launch uses the scratch set of (scene, stream); the mutex is held until everything is
@@ -902,8 +842,9 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (!sc) return RTK_AMD_ERR_OOM;
 
 	// spill area for rays whose stack outgrows LDS
-	const size_t lanes = blocks * BLOCK_THREADS;
-	const size_t lds_entries = packet ? 16 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
+	// (the pool kernel keeps fewer entries per ray in LDS; the rtk_trace_kernel pass behind it shares the area: its lanes x its entries fit)
+	const size_t lanes = pool ? std::max(blocks * BLOCK_THREADS, pool_blocks * (size_t)rtk_pool_slots()) : blocks * BLOCK_THREADS;
+	const size_t lds_entries = packet ? 16 : pool ? (size_t)rtk_pool_lds_stack() : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
 	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
 	if (spill_cap && (sc->spill_lanes < lanes || sc->spill_entries_per_lane < spill_cap)) {
 		// an earlier launch on this stream may still be using the old area
@@ -980,7 +921,40 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		const size_t left_blocks = std::min<size_t>(blocks, (size_t)ds->num_cus * 2u);
 		rtk_packet_launch(p, (unsigned)left_blocks, stream, false);
 	} else if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
-	else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
+	else if (pool) {
+		if (sc->leftover_capacity < n * 2u) {           // (counted in uint32: the list holds one 8-byte word per left-over ray)
+			if (sc->d_leftover) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_leftover); }
+			sc->d_leftover = nullptr;
+			sc->leftover_capacity = 0;
+			RTK_HIP_CHECK(hipMalloc(&sc->d_leftover, n * sizeof(unsigned long long)), RTK_AMD_ERR_OOM);
+			sc->leftover_capacity = n * 2u;
+		}
+		p.pool_leftover = reinterpret_cast<unsigned long long *>(sc->d_leftover);
+		const int rc = rtk_pool_launch(p, (unsigned)pool_blocks, stream, any_hit);
+		if (rc != RTK_AMD_OK) return rc;
+#ifdef POOL_STATS
+		{
+			unsigned long long c[32];
+			(void)hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream);
+			(void)hipStreamSynchronize(stream);
+			const double per64 = (double)n / 64.0;
+			fprintf(stderr, "pool stats per 64 rays: node trips %.2f (fill %.1f, node steps %.1f lanes) leaf trips %.2f (fill %.1f) set-up trips %.2f | claim spins %.2f | clk per trip: node %.0f leaf %.0f set-up %.0f claim %.0f\n",
+				c[1] / per64, c[1] ? (double)c[4] / c[1] : 0.0, c[1] ? (double)c[8] / c[1] : 0.0, c[2] / per64, c[2] ? (double)c[5] / c[2] : 0.0, c[3] / per64, c[7] / per64,
+				c[1] ? (double)c[9] / c[1] : 0.0, c[2] ? (double)c[13] / c[2] : 0.0, c[3] ? (double)c[14] / c[3] : 0.0, (double)c[15] / (double)(c[1] + c[2] + c[3] + 1));
+			fprintf(stderr, "   lost claims per trip %.2f | node trip clk: slot %.0f, state + pop %.0f, node step %.0f, write-back %.0f, pushes %.0f\n", (double)c[0] / (double)(c[1] + c[2] + c[3] + 1),
+				(double)c[10] / c[1], (double)c[11] / c[1], (double)c[24] / c[1], ((double)c[9] - c[10] - c[11] - c[24] - c[25]) / c[1], (double)c[25] / c[1]);
+			(void)hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream);
+		}
+#endif
+		// the rays it left over (none in most batches: a small grid that finds an empty list costs next to nothing)
+		TraceParams lp = p;
+		lp.perm = p.pool_leftover;
+		lp.n_indirect = p.counter + RTK_POOL_LEFTOVER_WORD;
+		lp.n = 0;
+		lp.spill_stride = (uint32_t)(spill_cap ? sc->spill_lanes : 0);
+		const size_t left_blocks = std::min<size_t>(blocks, (size_t)ds->num_cus);
+		hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)left_blocks), dim3(BLOCK_THREADS), 0, stream, lp);
+	} else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	if (counted) {
 		unsigned long long c[16], err = 0;

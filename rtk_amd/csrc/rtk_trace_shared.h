@@ -39,6 +39,8 @@ struct TraceParams {
 	uint32_t *cand_count;          // MODE 2: how many of them are valid
 	uint32_t cand_k;
 	uint32_t tile_blocks;          // image batches: tiles are numbered block by block (8x8 tiles = 64x64 pixels), not row by row
+	unsigned long long *pool_leftover;      // pool kernel only: ray numbers it leaves to rtk_trace_kernel (rays with non-finite or zero components); count in counter[RTK_POOL_LEFTOVER_WORD]
+	const unsigned long long *n_indirect;   // rtk_trace_kernel: if set, the number of rays is read from here when the kernel starts (the list above)
 	const uint32_t *tile_list;     // packet kernel only: trace the tiles listed here (counter[RTK_LEFTOVER_COUNT_WORD] of them, dealt through
 	                               // counter[RTK_LEFTOVER_HEAD_WORD]) instead of all tiles: what the assembly kernel handed back
 };
@@ -46,6 +48,8 @@ struct TraceParams {
 // Scratch counter words of the hand-over from the assembly packet kernel (rtk_packet_hot.S) to the C++ one; cleared with the rest
 #define RTK_LEFTOVER_COUNT_WORD 10
 #define RTK_LEFTOVER_HEAD_WORD 11
+// ... and from the pool kernel (rtk_trace_pool.hip) to rtk_trace_kernel: how many rays it left over
+#define RTK_POOL_LEFTOVER_WORD 12
 
 // Kernel argument of rtk_packet_hot (rtk_packet_hot.S reads these offsets)
 struct PkHotParams {
@@ -100,6 +104,10 @@ __device__ __forceinline__ unsigned long long map_index(unsigned long long i, ui
 }
 
 
+// rtk_trace_pool.hip: rays in an LDS pool, one 1024-thread workgroup per CU
+int rtk_pool_slots();          // rays a workgroup holds (its share of the spill area: slots x spill entries)
+int rtk_pool_lds_stack();      // stack entries per ray it keeps in LDS
+int rtk_pool_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool any_hit);
 // rtk_trace_packet.hip
 int rtk_packet_occupancy(bool counted);
 void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool counted);

@@ -280,7 +280,7 @@ static void collapse() {
 }
 
 // ---- traversal with counters
-struct Cnt { uint64_t nodes = 0, leaves = 0, tris = 0, hits = 0; };
+struct Cnt { uint64_t nodes = 0, leaves = 0, tris = 0, hits = 0; uint64_t sp_hist[40] = {0}; uint64_t max_hist[40] = {0}; };
 static bool tri_hit(const Ray &r, const float *p, double &t) {
 	double e1[3], e2[3], pv[3], tv[3], qv[3];
 	for (int k = 0; k < 3; k++) { e1[k] = (double)p[3 + k] - p[k]; e2[k] = (double)p[6 + k] - p[k]; }
@@ -300,7 +300,7 @@ static void trace(const Ray &r, Cnt &c) {
 	float best = r.tmax; bool hit = false;
 	float rd[3] = { 1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2] };
 	struct E { float t; int ref; } stack[256]; int sp = 0;
-	int top = 0; float topt = 0;
+	int top = 0; float topt = 0; int maxsp = 0;
 	for (;;) {
 		if (top >= 0) {
 			const W &w = wide[top]; c.nodes++;
@@ -313,6 +313,7 @@ static void trace(const Ray &r, Cnt &c) {
 			if (ORDERMODE == 0) { for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); } }
 			else if (nh > 1) { int m = 0; for (int i = 1; i < nh; i++) if (key[i] < key[m]) m = i; std::swap(key[0], key[m]); std::swap(ref[0], ref[m]); }   // nearest first, rest in slot order
 			for (int i = nh - 1; i >= 1; i--) { stack[sp].t = key[i]; stack[sp].ref = ref[i]; sp++; }
+			c.sp_hist[std::min(sp, 39)]++; maxsp = std::max(maxsp, sp);
 			if (nh) { top = ref[0]; topt = key[0]; continue; }
 		} else {
 			const Leaf &l = leaves[~top]; c.leaves++;
@@ -322,7 +323,7 @@ static void trace(const Ray &r, Cnt &c) {
 		while (sp > 0) { sp--; if (stack[sp].t > best) continue; top = stack[sp].ref; got = true; break; }
 		if (!got) break;
 	}
-	(void)topt;
+	(void)topt; c.max_hist[std::min(maxsp, 39)]++;
 	if (hit) c.hits++;
 }
 
@@ -331,6 +332,7 @@ static void trace(const Ray &r, Cnt &c) {
 // by kind, so that changes of the traversal's SHAPE (entry points shared by a 64x64 block, child order, packet size) can be
 // priced before they are written for the GPU.
 struct PkCnt { uint64_t tiles = 0, steps[5] = {0,0,0,0,0}, pops = 0, pops_culled = 0, tri_steps = 0, pushes = 0, lane_nodes = 0, entries = 0, entry_culled = 0, pre_steps = 0, blocks = 0, entry_list = 0; };
+static int PK_ANY = 0;   // any-hit packets: a lane that found a hit takes no further part
 static int PK_BLOCKS = 0; static int PK_LANES = 64; static int PK_ENTRY_DEPTH = 0; static int PK_ORDER = 0; static int PK_ENTRY_MAX = 1 << 30;
 static std::vector<int> wdepth;   // depth of every wide node (root = 0)
 static std::vector<uint8_t> wperm;  // per node, per octant: child order (4 x 2 bits), by distance of the child box centre along the octant's diagonal
@@ -420,7 +422,7 @@ static void trace_packet(const std::vector<Ray> &rs, PkCnt &c, const std::vector
 			const Leaf &l = leaves[~top];
 			for (uint32_t p : l.prims) {
 				c.tri_steps++;
-				for (int i = 0; i < L; i++) if (live[i]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) { best[i] = (float)t; hit[i] = 1; } }
+				for (int i = 0; i < L; i++) if (live[i]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) { best[i] = PK_ANY ? -3e38f : (float)t; hit[i] = 1; } }
 			}
 			pop = true;
 		}
@@ -483,6 +485,329 @@ static void packet_lab(int W_, int H_, int nblocks) {
 	printf(" | t mismatches %llu\n", (unsigned long long)mism);
 }
 
+static std::vector<Ray> load_rays(const char *f);
+// packets of 64 CONSECUTIVE rays of a file (a sorted batch): wave-level steps per packet, and the same rays one by one
+static void trace_any(const Ray &r, Cnt &c) {
+	float rd[3] = { 1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2] };
+	struct E { float t; int ref; } stack[256]; int sp = 0; int top = 0;
+	for (;;) {
+		if (top >= 0) {
+			const W &w = wide[top]; c.nodes++; float key[8]; int ref[8]; int nh = 0;
+			for (int k = 0; k < w.n; k++) { float tn; if (slab(r, rd, w.b[k], r.tmax, tn)) { key[nh] = tn; ref[nh] = w.ref[k]; nh++; } }
+			for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
+			for (int i = nh - 1; i >= 1; i--) { stack[sp].t = key[i]; stack[sp].ref = ref[i]; sp++; }
+			if (nh) { top = ref[0]; continue; }
+		} else {
+			const Leaf &l = leaves[~top]; c.leaves++;
+			for (uint32_t p : l.prims) { c.tris++; double t; if (tri_hit(r, &tris[9 * (size_t)p], t) && t > r.tmin && t < r.tmax) { c.hits++; return; } }
+		}
+		if (!sp) return;
+		top = stack[--sp].ref;
+	}
+}
+static void packet_file_lab(const char *file) {
+	auto rays = load_rays(file);
+	PkCnt c; Cnt sc; uint64_t mixed = 0;
+#pragma omp parallel
+	{ PkCnt lc; Cnt ls; uint64_t lm = 0;
+#pragma omp for schedule(dynamic, 4)
+		for (long g = 0; g < (long)(rays.size() / 64); g++) {
+			std::vector<Ray> rs(rays.begin() + g * 64, rays.begin() + g * 64 + 64);
+			bool uni = true; for (auto &r : rs) for (int a = 0; a < 3; a++) uni &= (r.d[a] < 0) == (rs[0].d[a] < 0);
+			lm += !uni;
+			trace_packet(rs, lc, nullptr, nullptr);
+			for (auto &r : rs) { if (PK_ANY) trace_any(r, ls); else trace(r, ls); }
+		}
+#pragma omp critical
+		{ c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes; c.lane_nodes += lc.lane_nodes;
+		  sc.nodes += ls.nodes; sc.tris += ls.tris; sc.hits += ls.hits; mixed += lm; }
+	}
+	const double T = (double)c.tiles; const uint64_t st = c.steps[0] + c.steps[1] + c.steps[2] + c.steps[3] + c.steps[4];
+	printf("  %s: %s packets of 64 consecutive rays: per packet: node steps %.1f (n_any 0/1/2/3/4: %.1f %.1f %.1f %.1f %.1f) tri steps %.1f pushes %.1f pops %.1f (culled %.1f) lane use in node steps %.3f | mixed-sign packets %.3f | the same rays alone: nodes %.2f tris %.2f hit %.4f\n",
+		file, PK_ANY ? "any-hit" : "closest-hit", st / T, c.steps[0] / T, c.steps[1] / T, c.steps[2] / T, c.steps[3] / T, c.steps[4] / T, c.tri_steps / T, c.pushes / T, c.pops / T, c.pops_culled / T,
+		(double)c.lane_nodes / (64.0 * st), mixed / T, sc.nodes / (T * 64), sc.tris / (T * 64), sc.hits / (T * 64));
+}
+// ---- per-lane kernel simulation: the control flow of rtk_trace_kernel (one ray per lane, persistent waves that refill idle lanes)
+// on the CPU, counting wave-level node and triangle steps, so that scheduling policies (when to leave the node loop, postponed
+// leaves, re-binning rays across the waves of a workgroup) can be priced before they are written for the GPU.
+struct LRay {
+	Ray r; float rd[3]; float best; bool hit; bool active;
+	int top; enum { NONE = INT32_MIN, RETRY = INT32_MIN + 1 };
+	struct E { float t; int ref; } stack[128]; int sp;
+	int tri_i;                 // next triangle of the leaf `top`
+	int pend[8]; float pendt[8]; int npend;     // postponed leaves (nearest first is not kept: order of arrival)
+};
+struct LCnt { uint64_t rays = 0, node_steps = 0, tri_steps = 0, pop_trips = 0, lane_nodes = 0, lane_tris = 0, refills = 0, rebins = 0, moved = 0; };
+static inline bool l_is_node(int top) { return top >= 0; }
+static inline bool l_is_leaf(int top) { return top < 0 && top != LRay::NONE && top != LRay::RETRY; }
+static void l_start(LRay &s, const Ray &r) { s.r = r; for (int a = 0; a < 3; a++) s.rd[a] = 1.0f / r.d[a]; s.best = r.tmax; s.hit = false; s.active = true; s.top = 0; s.sp = 0; s.tri_i = 0; s.npend = 0; }
+static void l_pop(LRay &s) { if (s.sp == 0) { s.top = LRay::NONE; return; } s.sp--; s.top = s.stack[s.sp].t > s.best ? (int)LRay::RETRY : s.stack[s.sp].ref; s.tri_i = 0; }
+static bool L_NODE_DEFER_POP = false;
+static void l_node(LRay &s) {
+	const W &w = wide[s.top]; float key[8]; int ref[8]; int nh = 0;
+	for (int k = 0; k < w.n; k++) {
+		float tn = s.r.tmin, tf = s.best;
+		for (int a = 0; a < 3; a++) { float t0 = (w.b[k].mn[a] - s.r.o[a]) * s.rd[a], t1 = (w.b[k].mx[a] - s.r.o[a]) * s.rd[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+		if (tn <= tf) { key[nh] = tn; ref[nh] = w.ref[k]; nh++; }
+	}
+	for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
+	for (int i = nh - 1; i >= 1; i--) { s.stack[s.sp].t = key[i]; s.stack[s.sp].ref = ref[i]; s.sp++; }
+	if (nh) { s.top = ref[0]; s.tri_i = 0; } else if (L_NODE_DEFER_POP) s.top = LRay::RETRY; else l_pop(s);
+}
+// one triangle of the leaf `leaf`; returns true when the leaf is finished
+static bool l_tri(LRay &s, int leaf, int &i) {
+	const Leaf &l = leaves[~leaf];
+	double t; const uint32_t p = l.prims[i];
+	if (tri_hit(s.r, &tris[9 * (size_t)p], t) && t > s.r.tmin && t < s.best) { s.best = (float)t; s.hit = true; }
+	return ++i >= (int)l.prims.size();
+}
+
+static int WS_NODE_EXIT = 32, WS_REFILL_MIN = 8, WS_WAVES = 32, WS_GROUP = 4, WS_POSTPONE = 0, WS_REBIN_EVERY = 1, WS_TRI_MIN = 1;
+
+// mode 0: the kernel as it stands
+static void wave_lab_current(const std::vector<Ray> &rays, LCnt &c) {
+	size_t next = 0;   // chunks of 64 in order, dealt to whichever wave asks next
+	struct Wave { LRay l[64]; size_t w_next = 0, w_end = 0; bool done = false; };
+	std::vector<Wave> waves(WS_WAVES);
+	for (auto &w : waves) for (auto &l : w.l) { l.active = false; l.top = LRay::NONE; }
+	size_t live = waves.size();
+	while (live) for (auto &w : waves) {
+		if (w.done) continue;
+		// ---- refill
+		int n_idle = 0; for (auto &l : w.l) n_idle += !l.active;
+		const bool pool_left = w.w_next < w.w_end || next < rays.size();
+		if (n_idle == 64 || (n_idle >= WS_REFILL_MIN && pool_left)) {
+			if (w.w_next >= w.w_end && next < rays.size()) { w.w_next = next; w.w_end = std::min(rays.size(), next + 64); next = w.w_end; }
+			size_t avail = w.w_end - w.w_next;
+			if (avail) { c.refills++; for (auto &l : w.l) if (!l.active && w.w_next < w.w_end) { l_start(l, rays[w.w_next++]); c.rays++; } }
+			bool any = false; for (auto &l : w.l) any |= l.active;
+			if (!any) { if (!(w.w_next < w.w_end || next < rays.size())) { w.done = true; live--; } continue; }
+		}
+		// ---- node loop
+		for (;;) {
+			for (auto &l : w.l) if (l.active && l.top == LRay::RETRY) l_pop(l);
+			int n_node = 0, n_leaf = 0, n_retry = 0;
+			for (auto &l : w.l) if (l.active) { n_node += l_is_node(l.top); n_leaf += l_is_leaf(l.top); n_retry += l.top == LRay::RETRY; }
+			if (n_node == 0) { if (n_retry) { c.pop_trips++; continue; } break; }
+			if (n_node < WS_NODE_EXIT && n_leaf) break;
+			c.node_steps++;
+			for (auto &l : w.l) if (l.active && l_is_node(l.top)) { c.lane_nodes++; l_node(l); }
+		}
+		// ---- leaves: one triangle per step, the wave leaves when its longest leaf is done
+		for (;;) {
+			int n = 0;
+			for (auto &l : w.l) if (l.active && l_is_leaf(l.top)) { n++; c.lane_tris++; if (l_tri(l, l.top, l.tri_i)) l_pop(l); else continue; }
+			if (!n) break;
+			c.tri_steps++;
+			bool more = false; for (auto &l : w.l) if (l.active && l_is_leaf(l.top) && l.tri_i > 0) more = true;
+			if (!more) break;
+		}
+		for (auto &l : w.l) if (l.active && l.top == LRay::NONE) l.active = false;
+	}
+}
+
+// mode 1: a workgroup of WS_GROUP waves re-bins its rays by state before every WS_REBIN_EVERY-th step: node rays to the low lanes,
+// leaf rays behind them; a wave does the step its majority wants (ties: node)
+static void wave_lab_rebin(const std::vector<Ray> &rays, LCnt &c) {
+	const int G = WS_GROUP * 64;
+	size_t next = 0;
+	const int ngroups = std::max(1, WS_WAVES / WS_GROUP);
+	std::vector<std::vector<LRay>> groups(ngroups, std::vector<LRay>(G));
+	for (auto &g : groups) for (auto &l : g) { l.active = false; l.top = LRay::NONE; }
+	std::vector<bool> done(ngroups, false); int live = ngroups; std::vector<uint64_t> round(ngroups, 0);
+	while (live) for (int gi = 0; gi < ngroups; gi++) {
+		if (done[gi]) continue;
+		auto &g = groups[gi];
+		// retire + refill (per wave, when at least WS_REFILL_MIN of its lanes are idle)
+		for (auto &l : g) if (l.active && l.top == LRay::NONE) l.active = false;
+		for (int w = 0; w < WS_GROUP; w++) {
+			int n_idle = 0; for (int i = 0; i < 64; i++) n_idle += !g[w * 64 + i].active;
+			if (n_idle >= WS_REFILL_MIN && next < rays.size()) { c.refills++; for (int i = 0; i < 64; i++) { LRay &l = g[w * 64 + i]; if (!l.active && next < rays.size()) { l_start(l, rays[next++]); c.rays++; } } }
+		}
+		bool any = false; for (auto &l : g) any |= l.active;
+		if (!any) { if (next >= rays.size()) { done[gi] = true; live--; } continue; }
+		for (auto &l : g) if (l.active && l.top == LRay::RETRY) l_pop(l);
+		if (WS_REBIN_EVERY > 0 && round[gi]++ % WS_REBIN_EVERY == 0) {
+			// stable partition: node | retry/none | leaf  (leaves at the far end, so that both ends fill whole waves)
+			std::vector<LRay> a, b, d; a.reserve(G); 
+			for (auto &l : g) { if (l.active && l_is_node(l.top)) a.push_back(l); else if (l.active && l_is_leaf(l.top)) d.push_back(l); else b.push_back(l); }
+			size_t k = 0; for (auto &l : a) g[k++] = l; for (auto &l : b) g[k++] = l; for (auto &l : d) g[k++] = l;
+			c.rebins++;
+		}
+		for (int w = 0; w < WS_GROUP; w++) {
+			int n_node = 0, n_leaf = 0;
+			for (int i = 0; i < 64; i++) { LRay &l = g[w * 64 + i]; if (l.active) { n_node += l_is_node(l.top); n_leaf += l_is_leaf(l.top); } }
+			if (n_node == 0 && n_leaf == 0) { c.pop_trips++; continue; }
+			if (n_node >= n_leaf && n_node >= 1 && !(n_leaf >= WS_TRI_MIN && n_node < WS_NODE_EXIT)) {
+				c.node_steps++;
+				for (int i = 0; i < 64; i++) { LRay &l = g[w * 64 + i]; if (l.active && l_is_node(l.top)) { c.lane_nodes++; l_node(l); } }
+			} else if (n_leaf) {
+				c.tri_steps++;
+				for (int i = 0; i < 64; i++) { LRay &l = g[w * 64 + i]; if (l.active && l_is_leaf(l.top)) { c.lane_tris++; if (l_tri(l, l.top, l.tri_i)) l_pop(l); } }
+			} else {
+				c.node_steps++;
+				for (int i = 0; i < 64; i++) { LRay &l = g[w * 64 + i]; if (l.active && l_is_node(l.top)) { c.lane_nodes++; l_node(l); } }
+			}
+		}
+	}
+}
+
+// mode 2: postponed leaves: a lane that reaches a leaf parks it (up to WS_POSTPONE of them) and pops on; parked leaves are
+// tested when at least WS_TRI_MIN lanes are blocked (list full or stack empty) or fewer than WS_NODE_EXIT lanes want nodes
+static void wave_lab_postpone(const std::vector<Ray> &rays, LCnt &c) {
+	size_t next = 0;
+	struct Wave { LRay l[64]; bool done = false; };
+	std::vector<Wave> waves(WS_WAVES);
+	for (auto &w : waves) for (auto &l : w.l) { l.active = false; l.top = LRay::NONE; l.npend = 0; }
+	size_t live = waves.size();
+	while (live) for (auto &w : waves) {
+		if (w.done) continue;
+		int n_idle = 0; for (auto &l : w.l) n_idle += !l.active;
+		if ((n_idle == 64 || n_idle >= WS_REFILL_MIN) && next < rays.size()) { c.refills++; for (auto &l : w.l) if (!l.active && next < rays.size()) { l_start(l, rays[next++]); c.rays++; } }
+		bool any = false; for (auto &l : w.l) any |= l.active;
+		if (!any) { if (next >= rays.size()) { w.done = true; live--; } continue; }
+		// park leaves / pops
+		for (auto &l : w.l) if (l.active) {
+			if (l.top == LRay::RETRY) l_pop(l);
+			if (l_is_leaf(l.top) && l.npend < WS_POSTPONE) { l.pend[l.npend++] = l.top; l_pop(l); }
+		}
+		int n_node = 0, n_blocked = 0, n_pend = 0;
+		for (auto &l : w.l) if (l.active) { n_node += l_is_node(l.top); const bool blocked = l_is_leaf(l.top) || (l.top == LRay::NONE && l.npend); n_blocked += blocked; n_pend += l.npend > 0 || l_is_leaf(l.top); }
+		if (n_node && !(n_blocked >= WS_TRI_MIN && n_node < WS_NODE_EXIT) ) {
+			c.node_steps++;
+			for (auto &l : w.l) if (l.active && l_is_node(l.top)) { c.lane_nodes++; l_node(l); }
+		} else if (n_pend) {
+			// every lane with a parked (or current) leaf tests ONE leaf's triangles; steps = the longest
+			int steps = 0;
+			for (auto &l : w.l) if (l.active) {
+				int leaf; bool cur = false;
+				if (l.npend) { leaf = l.pend[0]; for (int k = 1; k < l.npend; k++) l.pend[k - 1] = l.pend[k]; l.npend--; }
+				else if (l_is_leaf(l.top)) { leaf = l.top; cur = true; }
+				else continue;
+				int i = 0, n = 0; for (;;) { n++; c.lane_tris++; if (l_tri(l, leaf, i)) break; }
+				steps = std::max(steps, n);
+				if (cur) l_pop(l);
+				else if (l.top == LRay::NONE && l.sp == 0 && l.npend == 0) {}
+				// a node or entry that the new best culls is dropped by the next pop / slab test as usual
+				if (l_is_node(l.top) == false && l.top != LRay::NONE && l.top != LRay::RETRY && false) {}
+			}
+			c.tri_steps += steps;
+		} else c.pop_trips++;
+		for (auto &l : w.l) if (l.active && l.top == LRay::NONE && l.npend == 0) l.active = false;
+	}
+}
+
+// mode 3: the ray pool. Ray state lives in LDS slots; every trip a wave claims up to 64 rays that all want the same kind of step
+// (node / triangle / set-up of a new ray) from the workgroup's queues, does that step at (nearly) full lane use, and hands every ray
+// to the queue of its next state. Discrete-event simulation: WS_WAVES waves of one workgroup on four SIMDs, a step = compute
+// (vector instructions x 4 clk, exclusive on its SIMD) after a memory wait of WS_LAT clk during which the SIMD is free.
+static int WS_POPS = 3;
+static int WS_POOL = 1280, WS_LAT = 1500, WS_LEAF_FIRST = 1, WS_MIN_BATCH = 64;
+static void wave_lab_pool(const std::vector<Ray> &rays, LCnt &c, double &simd_busy, double &total_clk, double &valu) {
+	const int P = WS_POOL, NW = WS_WAVES; L_NODE_DEFER_POP = !(WS_POPS & 2);
+	std::vector<LRay> pool(P);
+	std::vector<int> q[3];   // 0 node, 1 leaf, 2 free
+	for (int i = 0; i < P; i++) { pool[i].active = false; q[2].push_back(i); }
+	size_t next = 0; size_t retired = 0;
+	struct Wv { double t; int phase; int kind; std::vector<int> batch; };   // phase 0: idle (wants a batch at time t); 1: waiting for memory until t, then needs its SIMD
+	std::vector<Wv> wv(NW); for (auto &w : wv) { w.t = 0; w.phase = 0; }
+	double simd_free[4] = { 0, 0, 0, 0 }, busy = 0; valu = 0;
+	const double COST_ISSUE = 45, COST_NODE = 135, COST_TRI = 115, COST_SETUP = 200, COST_POP = 12;
+	double now = 0; uint64_t guard = 0;
+	while (retired < rays.size() && guard++ < (1ull << 40)) {
+		// next event: the wave with the smallest time
+		int wi = 0; for (int i = 1; i < NW; i++) if (wv[i].t < wv[wi].t) wi = i;
+		Wv &w = wv[wi]; now = w.t; const int sd = wi & 3;
+		if (w.phase == 0) {
+			// claim a batch
+			const size_t nn = q[0].size(), nl = q[1].size(), nf = next < rays.size() ? q[2].size() : 0;
+			int kind = -1;
+			const size_t mb = (size_t)WS_MIN_BATCH;
+			if (WS_LEAF_FIRST && nl >= mb) kind = 1; else if (nn >= mb) kind = 0; else if (nl >= mb) kind = 1; else if (nf >= mb) kind = 2;
+			else {
+				// nothing fills a wave: take the fullest queue only if nobody else is about to deliver (all other waves idle) -- else wait
+				bool others_busy = false; for (int i = 0; i < NW; i++) if (i != wi && wv[i].phase == 1) others_busy = true;
+				const size_t best = std::max(nn, std::max(nl, nf));
+				if (best == 0 || (others_busy && best < mb)) { w.t = now + 200; if (!others_busy && best == 0) w.t = now + 1000; continue; }
+				kind = nn == best ? 0 : (nl == best ? 1 : 2);
+			}
+			auto &Q = q[kind]; const size_t k = std::min<size_t>(64, Q.size());
+			w.batch.assign(Q.begin(), Q.begin() + k); Q.erase(Q.begin(), Q.begin() + k);
+			w.kind = kind;
+			// issue part on the SIMD, then the memory wait
+			const double st = std::max(now, simd_free[sd]); simd_free[sd] = st + COST_ISSUE * 4; busy += COST_ISSUE * 4; valu += COST_ISSUE;
+			w.t = simd_free[sd] + (kind == 2 ? WS_LAT : WS_LAT); w.phase = 1;
+		} else {
+			// compute part
+			double cost = w.kind == 0 ? COST_NODE : (w.kind == 1 ? COST_TRI : COST_SETUP);
+			int extra_pops = 0;
+			if (w.kind == 0) { c.node_steps++; cost += COST_POP; for (int s : w.batch) { LRay &l = pool[s]; if (l.top == LRay::RETRY) l_pop(l); if (l_is_node(l.top)) { c.lane_nodes++; l_node(l); } } }
+			else if (w.kind == 1) { c.tri_steps++; for (int s : w.batch) { LRay &l = pool[s]; c.lane_tris++; if (l_tri(l, l.top, l.tri_i)) { if (WS_POPS & 1) l_pop(l); else l.top = LRay::RETRY; } } }
+			else { c.refills++; for (int s : w.batch) { if (next < rays.size()) { l_start(pool[s], rays[next++]); c.rays++; } else pool[s].top = LRay::NONE, pool[s].active = false; } }
+			cost += COST_POP * extra_pops;
+			const double st = std::max(now, simd_free[sd]); simd_free[sd] = st + cost * 4; busy += cost * 4; valu += cost;
+			for (int s : w.batch) { LRay &l = pool[s];
+				if (l_is_node(l.top) || l.top == LRay::RETRY) q[0].push_back(s); else if (l_is_leaf(l.top)) q[1].push_back(s);
+				else { if (l.active) { retired++; l.active = false; } q[2].push_back(s); } }
+			w.t = simd_free[sd]; w.phase = 0;
+		}
+	}
+	total_clk = now; simd_busy = busy / (4.0 * now);
+}
+
+// mode 4: every wave keeps WS_PER_LANE rays per lane in LDS (slot = k * 64 + lane: no ray ever changes lane, so no queues, no
+// atomics, no waiting on other waves, conflict-free LDS); each trip the wave picks the kind of step most lanes can take part in and
+// every lane works on the first of its rays that wants that step.
+static int WS_PER_LANE = 2, WS_LEAF_MIN = 40, WS_SETUP_MIN = 24;
+static void wave_lab_private(const std::vector<Ray> &rays, LCnt &c, double &valu) {
+	const int K = WS_PER_LANE;
+	size_t next = 0; valu = 0;
+	struct Wave { std::vector<LRay> l; bool done = false; };
+	std::vector<Wave> waves(WS_WAVES);
+	for (auto &w : waves) { w.l.resize(64 * K); for (auto &l : w.l) { l.active = false; l.top = LRay::NONE; } }
+	size_t live = waves.size();
+	const double COST_ISSUE = 40, COST_NODE = 145, COST_TRI = 115, COST_SETUP = 200;
+	while (live) for (auto &w : waves) {
+		if (w.done) continue;
+		int cN = 0, cL = 0, cF = 0, any = 0;
+		for (int i = 0; i < 64; i++) { bool n = false, lf = false, f = false; for (int k = 0; k < K; k++) { LRay &l = w.l[k * 64 + i]; if (!l.active) f = true; else { any++; if (l_is_node(l.top) || l.top == LRay::RETRY) n = true; else if (l_is_leaf(l.top)) lf = true; } } cN += n; cL += lf; cF += f; }
+		const bool more = next < rays.size();
+		if (!any && !more) { w.done = true; live--; continue; }
+		int kind;
+		if (cL >= WS_LEAF_MIN) kind = 1; else if (more && cF >= WS_SETUP_MIN && (cF >= 48 || cN < 48)) kind = 2; else if (cN >= 1 && cN >= cL) kind = 0; else if (cL) kind = 1; else if (more && cF) kind = 2; else kind = 0;
+		valu += COST_ISSUE;
+		if (kind == 0) { c.node_steps++; valu += COST_NODE; for (int i = 0; i < 64; i++) for (int k = 0; k < K; k++) { LRay &l = w.l[k * 64 + i]; if (l.active && (l_is_node(l.top) || l.top == LRay::RETRY)) { if (l.top == LRay::RETRY) l_pop(l); if (l_is_node(l.top)) { c.lane_nodes++; l_node(l); } break; } } }
+		else if (kind == 1) { c.tri_steps++; valu += COST_TRI; for (int i = 0; i < 64; i++) for (int k = 0; k < K; k++) { LRay &l = w.l[k * 64 + i]; if (l.active && l_is_leaf(l.top)) { c.lane_tris++; if (l_tri(l, l.top, l.tri_i)) l_pop(l); break; } } }
+		else { c.refills++; valu += COST_SETUP; for (int i = 0; i < 64; i++) for (int k = 0; k < K; k++) { LRay &l = w.l[k * 64 + i]; if (!l.active) { if (next < rays.size()) { l_start(l, rays[next++]); c.rays++; } break; } } }
+		for (auto &l : w.l) if (l.active && l.top == LRay::NONE) l.active = false;
+	}
+}
+
+static void wave_lab(int mode) {
+	auto rays = load_rays("rays_inc.bin");
+	LCnt c;
+	if (mode == 3) {
+		double sb, clk, valu; wave_lab_pool(rays, c, sb, clk, valu);
+		const double per64 = (double)c.rays / 64.0;
+		printf("  ray pool (%d slots, %d waves, latency %d clk, leaf first %d, min batch %d): per 64 rays: node trips %.2f tri trips %.2f set-up trips %.2f | lane use: node %.3f tri %.3f | vector instructions per 64 rays %.0f | SIMD busy %.3f | clk per 64 rays per CU %.0f\n",
+			WS_POOL, WS_WAVES, WS_LAT, WS_LEAF_FIRST, WS_MIN_BATCH, c.node_steps / per64, c.tri_steps / per64, c.refills / per64, c.lane_nodes / (64.0 * c.node_steps), c.lane_tris / (64.0 * c.tri_steps), valu / per64, sb, clk / per64);
+		return;
+	}
+	if (mode == 4) {
+		double valu; wave_lab_private(rays, c, valu);
+		const double per64 = (double)c.rays / 64.0;
+		printf("  %d rays per lane (leaf trip at %d lanes, set-up at %d): per 64 rays: node trips %.2f tri trips %.2f set-up trips %.2f | lane use: node %.3f tri %.3f | vector instructions per 64 rays %.0f\n",
+			WS_PER_LANE, WS_LEAF_MIN, WS_SETUP_MIN, c.node_steps / per64, c.tri_steps / per64, c.refills / per64, c.lane_nodes / (64.0 * c.node_steps), c.lane_tris / (64.0 * c.tri_steps), valu / per64);
+		return;
+	}
+	if (mode == 0) wave_lab_current(rays, c); else if (mode == 1) wave_lab_rebin(rays, c); else wave_lab_postpone(rays, c);
+	const double per64 = (double)c.rays / 64.0;
+	printf("  wave lab mode %d (node_exit %d refill_min %d waves %d group %d postpone %d rebin_every %d tri_min %d): per 64 rays: node steps %.2f tri steps %.2f pop trips %.2f refills %.2f | per ray: nodes %.2f tris %.2f | lane use: node %.3f tri %.3f | cost(190/130) %.0f\n",
+		mode, WS_NODE_EXIT, WS_REFILL_MIN, WS_WAVES, WS_GROUP, WS_POSTPONE, WS_REBIN_EVERY, WS_TRI_MIN, c.node_steps / per64, c.tri_steps / per64, c.pop_trips / per64, c.refills / per64,
+		(double)c.lane_nodes / c.rays, (double)c.lane_tris / c.rays, c.lane_nodes / (64.0 * c.node_steps), c.lane_tris / (64.0 * c.tri_steps),
+		(190.0 * c.node_steps + 130.0 * c.tri_steps + 20.0 * c.pop_trips + 150.0 * c.refills) / per64);
+}
+
 static std::vector<Ray> load_rays(const char *f) { FILE *fp = fopen(f, "rb"); fseek(fp, 0, SEEK_END); long s = ftell(fp); fseek(fp, 0, SEEK_SET); std::vector<Ray> r(s / 32); if (fread(r.data(), 32, r.size(), fp) != r.size()) abort(); fclose(fp); return r; }
 
 static double tree_sah() {
@@ -493,7 +818,7 @@ static double tree_sah() {
 }
 
 int main(int argc, char **argv) {
-	const char *trisf = "tris_1m.f32"; std::string builder = "lbvh"; int R = 16;
+	const char *trisf = "tris_1m.f32"; std::string builder = "lbvh"; int R = 16; int ws_mode = -1; std::vector<const char *> pk_files; bool skip_rays = false;
 	for (int i = 1; i < argc; i++) {
 		if (!strcmp(argv[i], "-b")) builder = argv[++i];
 		else if (!strcmp(argv[i], "-r")) R = atoi(argv[++i]);
@@ -513,6 +838,25 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-pe")) PK_ENTRY_DEPTH = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-po")) PK_ORDER = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-pb")) PK_BLOCKS = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-ws")) ws_mode = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-pf")) pk_files.push_back(argv[++i]);
+		else if (!strcmp(argv[i], "-pa")) PK_ANY = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-norays")) skip_rays = true;
+		else if (!strcmp(argv[i], "-wne")) WS_NODE_EXIT = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wrm")) WS_REFILL_MIN = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-ww")) WS_WAVES = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wg")) WS_GROUP = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wp")) WS_POSTPONE = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wre")) WS_REBIN_EVERY = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wtm")) WS_TRI_MIN = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wpool")) WS_POOL = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wpops")) WS_POPS = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wpl")) WS_PER_LANE = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wlm")) WS_LEAF_MIN = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wsm")) WS_SETUP_MIN = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wlat")) WS_LAT = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wlf")) WS_LEAF_FIRST = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-wmb")) WS_MIN_BATCH = atoi(argv[++i]);
 	}
 	{ FILE *fp = fopen(trisf, "rb"); fseek(fp, 0, SEEK_END); long s = ftell(fp); fseek(fp, 0, SEEK_SET); tris.resize(s / 4); if (fread(tris.data(), 4, tris.size(), fp) != tris.size()) abort(); fclose(fp); N = tris.size() / 9; }
 	morton_sort();
@@ -528,17 +872,20 @@ int main(int argc, char **argv) {
 	collapse();
 	size_t ntl = 0; for (auto &l : leaves) ntl += l.prims.size();
 	printf("%s R=%d cn=%.2f ml=%u cm=%d: build %.2fs wide %zu leaves %zu (%.2f tris/leaf) sah4 %.2f\n", builder.c_str(), R, CN, MAXLEAF, COLLAPSE_MODE, bt, wide.size(), leaves.size(), (double)ntl / leaves.size(), tree_sah());
-	for (const char *rf : { "rays_coh.bin", "rays_inc.bin" }) {
+	if (!skip_rays) for (const char *rf : { "rays_coh.bin", "rays_inc.bin" }) {
 		auto rays = load_rays(rf); Cnt c;
 #pragma omp parallel
 		{ Cnt lc;
 #pragma omp for schedule(dynamic, 256)
 			for (long i = 0; i < (long)rays.size(); i++) trace(rays[i], lc);
 #pragma omp critical
-			{ c.nodes += lc.nodes; c.leaves += lc.leaves; c.tris += lc.tris; c.hits += lc.hits; } }
+			{ c.nodes += lc.nodes; c.leaves += lc.leaves; c.tris += lc.tris; c.hits += lc.hits; for (int k = 0; k < 40; k++) { c.sp_hist[k] += lc.sp_hist[k]; c.max_hist[k] += lc.max_hist[k]; } } }
 		double n = (double)rays.size();
 		printf("  %-14s nodes %.2f leaves %.2f tris %.2f hit %.4f\n", rf, c.nodes / n, c.leaves / n, c.tris / n, c.hits / n);
+		printf("     stack depth after a node step (share of steps), depth 0..: "); for (int k = 0; k < 24; k++) printf("%.3f ", (double)c.sp_hist[k] / c.nodes); printf("\n     deepest stack of a ray (share of rays): "); for (int k = 0; k < 24; k++) printf("%.3f ", c.max_hist[k] / n); printf("\n");
 	}
 	if (PK_BLOCKS) packet_lab(4096, 4096, PK_BLOCKS);
+	if (ws_mode >= 0) wave_lab(ws_mode);
+	if (!pk_files.empty()) { wperm.assign(wide.size() * 8, 0xe4); for (const char *f : pk_files) packet_file_lab(f); }
 	return 0;
 }
