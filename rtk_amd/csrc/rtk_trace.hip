@@ -54,7 +54,8 @@
 				const unsigned long long w_ = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p.spill + (size_t)(sp - LDS_STACK) * p.spill_stride + glane)); \
 				e_ = make_uint2((uint32_t)w_, (uint32_t)(w_ >> 32));                                                \
 			}                                                                                                   \
-			top = __uint_as_float(e_.x) > best_t ? RTK_REF_RETRY : e_.y;                                    \
+			/* (reference, entry distance). Any-hit: an entry never lies behind best_t, which stays max_t until the ray is over */ \
+			top = (MODE != 1 && __uint_as_float(e_.y) > best_t) ? RTK_REF_RETRY : e_.x;                                    \
 		}                                                                                                   \
 	} while (0)
 // One child of a node step: the lane enters it if its slab test passed and the slot is not empty; its key is the entry
@@ -217,12 +218,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 		for (;;) {
 			// Lanes that reached a leaf wait here for the others. When only a few lanes are
 			// still descending and leaves are waiting, go and do the leaves first.
-			const bool retry = active && top == RTK_REF_RETRY;
+			const bool retry = MODE != 1 && active && top == RTK_REF_RETRY;
 			if (retry) RTK_POP();
 			const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t)top >= 0) & m_active;
 			const bool want_node = __builtin_amdgcn_inverse_ballot_w64(m_node);
 			if (m_node == 0ull) {
-				if ((__builtin_amdgcn_ballot_w64(top == RTK_REF_RETRY) & m_active) != 0ull) continue;   // somebody is still popping
+				if (MODE != 1 && (__builtin_amdgcn_ballot_w64(top == RTK_REF_RETRY) & m_active) != 0ull) continue;   // somebody is still popping
 				break;
 			}
 			// (lanes still popping are not counted as descending: counting them was 1 % slower)
@@ -301,15 +302,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 			}
 			}
 			// nearest first (rtk.c:496-517 orders by entry distance)
-			cswap(key[0], ref[0], key[1], ref[1]);
-			cswap(key[2], ref[2], key[3], ref[3]);
-			cswap(key[0], ref[0], key[2], ref[2]);
-			cswap(key[1], ref[1], key[3], ref[3]);
-			cswap(key[1], ref[1], key[2], ref[2]);
+			// ... as a 5-comparator network on (distance, reference) PAIRS held as one 64-bit value each, distance in the high
+			// half: read as a double such a pair orders like its distance (the bit patterns of non-NaN floats order like their
+			// values under a sign-magnitude compare, which is what a double compare of the pair is; +inf, the key of a child that
+			// is not entered, becomes a large finite double; equal distances fall back on the reference, any order of which is
+			// right), so a comparator is one v_min_f64 and one v_max_f64 instead of a compare and four selects. No key is a NaN.
+			double pr[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++) pr[i] = __hiloint2double((int)__float_as_uint(key[i]), (int)ref[i]);
+			cswap_pair(pr[0], pr[1]);
+			cswap_pair(pr[2], pr[3]);
+			cswap_pair(pr[0], pr[2]);
+			cswap_pair(pr[1], pr[3]);
+			cswap_pair(pr[1], pr[2]);
 			if (nhit == 0u) {
 				RTK_POP();
 			} else {
-				top = ref[0];
+				top = (uint32_t)__double2loint(pr[0]);
 				const uint32_t np = nhit - 1u;              // sorted slots np..1 go on the stack, far to near
 				if (sp + 3u <= LDS_STACK) {
 					// Branch-free: rows sp..sp+2 all exist. Slot i <= np goes to row sp+np-i; the others (misses) are
@@ -317,14 +326,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 #pragma unroll
 					for (int i = 1; i <= 3; i++) {
 						const uint32_t row = sp + np - (uint32_t)i + ((uint32_t)i > np ? 3u : 0u);
-						stk[row][lane] = make_uint2(__float_as_uint(key[i]), ref[i]);
+						stk[row][lane] = make_uint2((uint32_t)__double2loint(pr[i]), (uint32_t)__double2hiint(pr[i]));
 					}
 					sp += np;
 				} else {
 #pragma unroll
 					for (int i = 3; i >= 1; i--) {
 						if (nhit > (uint32_t)i) {
-							const uint2 e = make_uint2(__float_as_uint(key[i]), ref[i]);
+							const uint2 e = make_uint2((uint32_t)__double2loint(pr[i]), (uint32_t)__double2hiint(pr[i]));
 							RTK_PUSH(e);
 						}
 					}
@@ -870,7 +879,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		}
 		unsigned long long *keys_a = (unsigned long long *)sc->d_sort, *keys_b = keys_a + sc->sort_capacity;
 		uint32_t *bounds = (uint32_t *)(keys_b + sc->sort_capacity), *scratch = bounds + 16;
-		static const uint32_t cell_bits = getenv("RTK_AMD_SORT_CELL_BITS") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_CELL_BITS")) : 5u;
+		static const uint32_t cell_bits = getenv("RTK_AMD_SORT_CELL_BITS") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_CELL_BITS")) : 7u;   // 2^7 cells per axis: 3.44 against 3.32 Grays/s at 2^5 on the shadow batch (profiles/r03_ab_sort_cells.log)
 		static const uint32_t with_octant = getenv("RTK_AMD_SORT_OCTANT") ? (uint32_t)atoi(getenv("RTK_AMD_SORT_OCTANT")) : 0u;
 		static const int entry_key = getenv("RTK_AMD_SORT_KEY") ? atoi(getenv("RTK_AMD_SORT_KEY")) : 1;   // 0: origin cell in the batch's origin bounds
 		if (entry_key && ds->view.num_nodes) {

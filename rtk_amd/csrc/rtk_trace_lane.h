@@ -73,6 +73,14 @@ __device__ __forceinline__ void load_qnode(const char *base, uint32_t a_node, f3
 
 __device__ __forceinline__ float ubyte_f32(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyteK
 
+// one comparator of a sorting network on 64-bit (key in the high half) pairs: see the node step of rtk_trace_kernel
+__device__ __forceinline__ void cswap_pair(double &a, double &b)
+{
+	double lo, hi;
+	asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b));
+	a = lo; b = hi;
+}
+
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb)
 {
 	const bool s = kb < ka;

@@ -494,7 +494,9 @@ static void trace_any(const Ray &r, Cnt &c) {
 		if (top >= 0) {
 			const W &w = wide[top]; c.nodes++; float key[8]; int ref[8]; int nh = 0;
 			for (int k = 0; k < w.n; k++) { float tn; if (slab(r, rd, w.b[k], r.tmax, tn)) { key[nh] = tn; ref[nh] = w.ref[k]; nh++; } }
-			for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); }
+			if (ORDERMODE == 0) { for (int i = 1; i < nh; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(ref[j], ref[j - 1]); } }
+			else if (ORDERMODE == 1 && nh > 1) { int m = 0; for (int i = 1; i < nh; i++) if (key[i] < key[m]) m = i; std::swap(key[0], key[m]); std::swap(ref[0], ref[m]); }   // nearest first, rest in slot order
+			// ORDERMODE 2: slot order
 			for (int i = nh - 1; i >= 1; i--) { stack[sp].t = key[i]; stack[sp].ref = ref[i]; sp++; }
 			if (nh) { top = ref[0]; continue; }
 		} else {
