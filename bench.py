@@ -70,6 +70,9 @@ def load_pmc_summary(workload):
     return None, None, False
 
 
+L2_MISS_CEILING_G_PER_S = 56.0
+
+
 def limiter_from_pmc(pj):
     """What the counters say bounds the kernel: share of cycles the VALU pipes are issuing, lane utilisation of
     those instructions, share of wave time spent waiting, L2 hit rate."""
@@ -99,6 +102,12 @@ def limiter_from_pmc(pj):
         out["wave_cycles_waiting"] = round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 3)
     if "l2_hit_rate" in pj:
         out["l2_hit_rate"] = round(pj["l2_hit_rate"], 3)
+    if m("TCC_MISS_sum") and ns:
+        # L2 misses per second against what the memory system gave a pure gather kernel (scripts/gather_probe.hip,
+        # profiles/r03_gather_probe.log: 56 G requests/s whether 16, 64 or 128 bytes of the line are used, from the Infinity
+        # Cache and from HBM alike, at 4 to 32 waves per CU)
+        out["l2_miss_g_per_s"] = round(m("TCC_MISS_sum") / ns, 1)
+        out["l2_miss_ceiling_g_per_s"] = L2_MISS_CEILING_G_PER_S
     return out
 
 
