@@ -605,9 +605,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 
 struct Climb { int cur_ref; int l; int r; };      // cur_ref: >= 0 inner node, < 0 leaf ~slot; INT_MIN: none
 
+// meet[node]: 0 until the first of the node's two subtrees has arrived, then (its reference << 32 | the range end it brings) + 1
+// (never 0: a range end is below 2^32 - 1). Which side it is the second arriver knows: the other one.
+__device__ __forceinline__ unsigned long long meet_word(int ref, int end) { return (((unsigned long long)(uint32_t)ref << 32) | (uint32_t)end) + 1ull; }
+
 __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
-	BinNode *bin, Climb *climbers, unsigned long long *half, uint32_t *arrive, int *root, BuildParams bp, float *area)
+	BinNode *bin, Climb *climbers, unsigned long long *meet, int *climb_idx, uint32_t *tile_nclimb, int *root, BuildParams bp, float *area)
 {
+	__shared__ uint32_t s_nclimb;
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
 	__shared__ uint32_t s_arrive[REFIT_TILE];
 	__shared__ int2 s_lr[REFIT_TILE];                            // children of node lo + k (x left, y right)
@@ -617,6 +622,7 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
 	const int t = (int)threadIdx.x;
 	s_arrive[t] = 0u;
+	if (t == 0) s_nclimb = 0u;
 	s_lr[t] = make_int2(INT_MIN, INT_MIN);
 	if (lo + t - 1 <= hi) s_delta[t] = key_delta(keys, n, lo + t - 1);
 	if (t == 0 && hi - lo + 1 == REFIT_TILE) s_delta[REFIT_TILE] = key_delta(keys, n, hi);
@@ -649,8 +655,12 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 			s_bin[k] = cur;
 		}
 		climbers[i] = left_over;
+		// ... and where pass 2 finds the tile's climbers without looking at every triangle: their positions, packed at the
+		// start of the tile's stretch of climb_idx (any order: the tree does not depend on who climbs first)
+		if (left_over.cur_ref != INT_MIN) climb_idx[lo + (int)atomicAdd(&s_nclimb, 1u)] = i;
 	}
 	__syncthreads();
+	if (t == 0) tile_nclimb[blockIdx.x] = s_nclimb;
 	if (i < hi && s_arrive[t] == 2u) {
 		bin[i] = s_bin[t];
 		if (area) area[i] = open_area(s_bin[t]);      // what the tile-local collapse ranks children by (4 bytes instead of the 32-byte record)
@@ -661,8 +671,7 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 		// is here over in the form pass 2 uses (plain stores, the kernel boundary publishes them)
 		const bool left_here = s_lr[t].x != INT_MIN;
 		const int ref = left_here ? s_lr[t].x : s_lr[t].y, end = left_here ? s_rl[t] : s_rr[t];
-		half[2 * (size_t)i + (left_here ? 0 : 1)] = ((unsigned long long)(uint32_t)ref << 32) | (uint32_t)end;
-		arrive[i] = 1u;
+		meet[i] = meet_word(ref, end);
 	}
 }
 
@@ -714,43 +723,46 @@ __device__ __forceinline__ BinNode bin_load(BinNode *src)
 	return v;
 }
 
-// half[node] = { left child | left range end , right child | right range end }: each half one 8-byte word
+// One 64-wide workgroup per tile takes the tile's climbers (a few to a few dozen; climb_idx / tile_nclimb from pass 1) -- the
+// launch used to cover every triangle to find them. Two subtrees meet at a node through ONE compare-and-swap on meet[node]:
+// the first arriver swaps its (reference, range end) in and is done, the second gets the first one's word back (round 2: an
+// exchange, a wait, a counter increment and a load -- three memory-side round trips per level of a chain that is ~20 levels deep).
 // never_leaf (tile mode): a node finished here -- one that reaches across a tile border -- is never ONE leaf. Its finished
 // children are the roots that k_collapse_tile turns into wide nodes (k_refit_tile counted them before this pass knew the
 // node's cost), so the node above them must stay a node: a leaf of two or three triangles straddling a border would
 // otherwise swallow a subtree that already has a number. (One such node at 17M triangles; found by the validator.)
-__global__ void k_refit_top(const DevTri *tris, int n, const unsigned long long *keys, const Climb *climbers, unsigned long long *half,
-	uint32_t *arrive, BinNode *bin, int2 *lr, uint2 *range, int *root, BuildParams bp, bool never_leaf)
+__global__ void __launch_bounds__(64) k_refit_top(const DevTri *tris, int n, const unsigned long long *keys, const Climb *climbers, const int *climb_idx,
+	const uint32_t *tile_nclimb, unsigned long long *meet, BinNode *bin, int2 *lr, uint2 *range, int *root, BuildParams bp, bool never_leaf)
 {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const Climb c = climbers[i];
-	if (c.cur_ref == INT_MIN) return;
-	int cur_ref = c.cur_ref, L = c.l, R = c.r;
-	BinNode cur = cur_ref < 0 ? leaf_record(tris, (uint32_t)~cur_ref, bp) : bin[cur_ref];      // finished by pass 1: plain load
-	for (;;) {
-		if (L == 0 && R == n - 1) { *root = cur_ref; return; }
-		const int dl = key_delta(keys, n, L - 1), dr = key_delta(keys, n, R);
-		const bool go_right = L == 0 || (R != n - 1 && dr > dl);
-		const int parent = go_right ? R : L - 1;
-		// this half: child reference and the range end it brings, then (inner nodes finished in THIS pass) its record
-		const unsigned long long mine = ((unsigned long long)(uint32_t)cur_ref << 32) | (uint32_t)(go_right ? L : R);
-		(void)__hip_atomic_exchange(half + 2 * (size_t)parent + (go_right ? 0 : 1), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		// everything this thread published is complete at the memory side before it announces itself
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const uint32_t old = __hip_atomic_fetch_add(&arrive[parent], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (old == 0u) return;
-		const unsigned long long theirs = mem_load64(half + 2 * (size_t)parent + (go_right ? 1 : 0));
-		const int sib = (int)(uint32_t)(theirs >> 32);
-		if (go_right) R = (int)(uint32_t)theirs; else L = (int)(uint32_t)theirs;
-		const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : bin_load(&bin[sib]);
-		cur = combine_records(cur, other, bp);
-		if (never_leaf) cur.cnt_flag &= 0x7fffffffu;
-		bin_store(&bin[parent], cur);
-		// topology of the finished node: read by the collapse only (later launches), plain stores
-		lr[parent] = go_right ? make_int2(cur_ref, sib) : make_int2(sib, cur_ref);
-		range[parent] = make_uint2((uint32_t)L, (uint32_t)R);
-		cur_ref = parent;
+	const int lo = (int)blockIdx.x * REFIT_TILE;
+	const uint32_t count = tile_nclimb[blockIdx.x];
+	for (uint32_t j = threadIdx.x; j < count; j += blockDim.x) {
+		const Climb c = climbers[climb_idx[lo + (int)j]];
+		int cur_ref = c.cur_ref, L = c.l, R = c.r;
+		BinNode cur = cur_ref < 0 ? leaf_record(tris, (uint32_t)~cur_ref, bp) : bin[cur_ref];      // finished by pass 1: plain load
+		for (;;) {
+			if (L == 0 && R == n - 1) { *root = cur_ref; break; }
+			const int dl = key_delta(keys, n, L - 1), dr = key_delta(keys, n, R);
+			const bool go_right = L == 0 || (R != n - 1 && dr > dl);
+			const int parent = go_right ? R : L - 1;
+			// (an inner node finished in THIS pass has its record at the memory side already: bin_store and the wait below)
+			unsigned long long seen = 0ull;
+			(void)__hip_atomic_compare_exchange_strong(meet + parent, &seen, meet_word(cur_ref, go_right ? L : R), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (seen == 0ull) break;                                           // first arriver: the sibling's thread carries on
+			const unsigned long long theirs = seen - 1ull;
+			const int sib = (int)(uint32_t)(theirs >> 32);
+			if (go_right) R = (int)(uint32_t)theirs; else L = (int)(uint32_t)theirs;
+			const BinNode other = sib < 0 ? leaf_record(tris, (uint32_t)~sib, bp) : bin_load(&bin[sib]);
+			cur = combine_records(cur, other, bp);
+			if (never_leaf) cur.cnt_flag &= 0x7fffffffu;
+			bin_store(&bin[parent], cur);
+			// topology of the finished node: read by the collapse only (later launches), plain stores
+			lr[parent] = go_right ? make_int2(cur_ref, sib) : make_int2(sib, cur_ref);
+			range[parent] = make_uint2((uint32_t)L, (uint32_t)R);
+			cur_ref = parent;
+			// everything this thread published is complete at the memory side before it announces the node one level up
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
 	}
 }
 
@@ -1662,7 +1674,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	need += padded((size_t)n * sizeof(BinNode));                                    // bin
 	need += padded((size_t)n * 16) + 2 * padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);   // collapse: dec, info, jobs, block sums, ring
 	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case; unused in tile mode)
-	need += 2 * padded(((size_t)n / REFIT_TILE + 4) * 4) + padded(16) + padded((size_t)n * 4);   // tile counts, tile bases, depth word, areas
+	need += 3 * padded(((size_t)n / REFIT_TILE + 4) * 4) + padded(16) + padded((size_t)n * 4);   // tile counts, tile bases, climbers per tile, depth word, areas
 	Workspace &ws = g_workspace[device];
 	std::lock_guard<std::mutex> ws_lock(ws.mutex);
 	if (ws.cap < need) {
@@ -1828,11 +1840,15 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	uint32_t *d_tile_count = ar.take<uint32_t>(num_tiles + 1u), *d_tile_base = ar.take<uint32_t>(num_tiles + 1u);
 	uint32_t *d_depth_word = ar.take<uint32_t>(4);
 	float *d_area = tile_mode ? ar.take<float>(n) : (float *)nullptr;
-	if (hipMemsetAsync(d_arrive, 0, (size_t)n * 4, bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
+	// pass 2 finds its climbers through d_arrive (their positions, packed per tile) and d_tile_nclimb; two subtrees meet through
+	// the first n words of d_half
+	uint32_t *d_tile_nclimb = ar.take<uint32_t>(num_tiles + 1u);
+	int *d_climb_idx = reinterpret_cast<int *>(d_arrive);
+	if (hipMemsetAsync(d_half, 0, (size_t)n * 8, bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
 	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
-		d_bin, d_climbers, d_half, d_arrive, d_root, bp, d_area);
-	hipLaunchKernelGGL(k_refit_top, dim3((n + 255u) / 256u), dim3(256), 0, bs, d_tris, (int)n, keys, d_climbers, d_half, d_arrive, d_bin, d_lr, d_range,
+		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area);
+	hipLaunchKernelGGL(k_refit_top, dim3(num_tiles), dim3(64), 0, bs, d_tris, (int)n, keys, d_climbers, d_climb_idx, d_tile_nclimb, d_half, d_bin, d_lr, d_range,
 		d_root, bp, tile_mode);
 	if (tile_mode) {
 		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, bs, (int)n, d_lr, d_range, d_area, d_climbers, d_tile_count);
