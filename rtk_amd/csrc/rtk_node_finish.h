@@ -26,22 +26,24 @@ __device__ __forceinline__ float grid_step(float extent)
 __device__ __forceinline__ void child_order(const DevNode &nd, uint32_t order[4])
 {
 	order[0] = order[1] = order[2] = order[3] = 0u;
+	float cx[4], cy[4], cz[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) { cx[k] = nd.bx[0][k] + nd.bx[1][k]; cy[k] = nd.by[0][k] + nd.by[1][k]; cz[k] = nd.bz[0][k] + nd.bz[1][k]; }
+#pragma unroll
 	for (uint32_t o = 0; o < 8u; o++) {
 		float key[4];
+#pragma unroll
 		for (int k = 0; k < 4; k++) {
-			const float cx = nd.bx[0][k] + nd.bx[1][k], cy = nd.by[0][k] + nd.by[1][k], cz = nd.bz[0][k] + nd.bz[1][k];
-			float s = ((o & 1u) ? -cx : cx) + ((o & 2u) ? -cy : cy) + ((o & 4u) ? -cz : cz);
+			float s = ((o & 1u) ? -cx[k] : cx[k]) + ((o & 2u) ? -cy[k] : cy[k]) + ((o & 4u) ? -cz[k] : cz[k]);
 			if (!(s == s)) s = INFINITY;                           // NaN boxes sort behind everything real
 			key[k] = nd.child[k] == RTK_REF_NONE ? INFINITY : s;
 		}
-		// rank of slot k = how many slots come before it
-		uint32_t word = 0u, pair = 0u, bit = 0u;
-		for (int i = 0; i < 4; i++) {
-			uint32_t rank = 0;
-			for (int j = 0; j < 4; j++) if (j != i && (key[j] < key[i] || (key[j] == key[i] && j < i))) rank++;
-			word |= (uint32_t)i << (2u * rank);
-			for (int j = i + 1; j < 4; j++, bit++) if (key[j] < key[i]) pair |= 1u << bit;   // the second of the pair comes first
-		}
+		// For the six pairs i < j: does i come before j? (ties go to the lower slot; no key is a NaN.) The rank of a slot = how
+		// many slots come before it; a pair bit says that the SECOND of the pair comes first.
+		const uint32_t b01 = key[0] <= key[1], b02 = key[0] <= key[2], b03 = key[0] <= key[3], b12 = key[1] <= key[2], b13 = key[1] <= key[3], b23 = key[2] <= key[3];
+		const uint32_t r0 = (1u - b01) + (1u - b02) + (1u - b03), r1 = b01 + (1u - b12) + (1u - b13), r2 = b02 + b12 + (1u - b23), r3 = b03 + b13 + b23;
+		uint32_t word = (0u << (2u * r0)) | (1u << (2u * r1)) | (2u << (2u * r2)) | (3u << (2u * r3));
+		const uint32_t pair = (1u - b01) | ((1u - b02) << 1) | ((1u - b03) << 2) | ((1u - b12) << 3) | ((1u - b13) << 4) | ((1u - b23) << 5);
 		word |= pair << RTK_ORDER_PAIR_SHIFT;
 		order[o >> 1] |= word << (16u * (o & 1u));
 	}
@@ -64,11 +66,18 @@ __device__ __forceinline__ bool quantize_node(const DevNode &nd, DevNodeQ &q)
 		for (int attempt = 0; attempt < 4; attempt++) {
 			bool fits = true;
 			wl = wh = 0;
+			// (the step is a power of two: multiplying by its reciprocal IS the division, bit for bit, without the divide's
+			// dozen instructions -- eight of them per axis were a quarter of what k_collapse_tile executes per node)
+			// (a step below 2^-126 -- a box whose extent is a denormal -- has no finite reciprocal: those divide)
+			const bool recip = s >= 0x1p-126f && s <= 0x1p126f;     // (and its reciprocal is a normal number too)
+			const float inv_s = recip ? 1.0f / s : 0.0f;
 			for (int k = 0; k < 4; k++) {
 				uint32_t ql = 255u, qh = 0u;                       // empty slot: inverted, can never be entered
 				if (nd.child[k] != RTK_REF_NONE) {
 					// floor / ceil in float, then made safe in double: org + q * s is exact there
-					float fl = floorf((lo[a][k] - mn) / s), fh = ceilf((hi[a][k] - mn) / s);
+					float fl, fh;
+					if (recip) { fl = floorf((lo[a][k] - mn) * inv_s); fh = ceilf((hi[a][k] - mn) * inv_s); }
+					else { fl = floorf((lo[a][k] - mn) / s); fh = ceilf((hi[a][k] - mn) / s); }
 					fl = fminf(fmaxf(fl, 0.0f), 255.0f);
 					fh = fminf(fmaxf(fh, 0.0f), 300.0f);
 					ql = (uint32_t)fl; qh = (uint32_t)fh;
