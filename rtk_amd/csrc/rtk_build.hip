@@ -1861,12 +1861,12 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	// tile mode (more than one refit tile): the subtrees inside a tile are collapsed by k_collapse_tile, only the nodes above
 	// them go through the level-by-level collapse.
 	const uint32_t num_tiles = (n + REFIT_TILE - 1u) / REFIT_TILE;
-	// Measured on MI355X (profiles/r03_build_*): 3.30 against 3.53 ms at 10M triangles, 0.69 against 0.63 ms at 1M -- the fixed cost
-	// of the extra launches (count, scan, the small top collapse) is not earned back below a few million triangles, so tile
-	// mode starts at 2M. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read per build) moves that: 0 = whenever there are two tiles,
-	// a huge value = never (everything level by level, the round-2 path: A/B).
+	// Measured on MI355X (profiles/r03_build_timing.log): 2.84 against 3.1 ms at 10M triangles, 1.94 / 2.05 at 6M, 1.48 / 1.50 at 4M,
+	// 1.23 / 1.20 at 3M, 0.69 / 0.62 at 1M -- the fixed cost of the extra launches (count, scan, the small top collapse) is not
+	// earned back below ~3.5 million triangles, where tile mode starts. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read per build)
+	// moves that: 0 = whenever there are two tiles, a huge value = never (everything level by level, the round-2 path: A/B).
 	const char *tile_env = getenv("RTK_AMD_TILE_COLLAPSE_MIN");
-	const uint64_t tile_min = tile_env ? (uint64_t)atoll(tile_env) : (1ull << 21);
+	const uint64_t tile_min = tile_env ? (uint64_t)atoll(tile_env) : (7ull << 19);
 	const bool tile_mode = num_tiles > 1u && (uint64_t)n >= tile_min;
 	uint32_t *d_tile_count = ar.take<uint32_t>(num_tiles + 1u), *d_tile_base = ar.take<uint32_t>(num_tiles + 1u);
 	uint32_t *d_depth_word = ar.take<uint32_t>(4);
