@@ -81,8 +81,16 @@ __device__ __forceinline__ bool quantize_node(const DevNode &nd, DevNodeQ &q)
 					fl = fminf(fmaxf(fl, 0.0f), 255.0f);
 					fh = fminf(fmaxf(fh, 0.0f), 300.0f);
 					ql = (uint32_t)fl; qh = (uint32_t)fh;
-					while (ql > 0u && (double)mn + (double)ql * (double)s > (double)lo[a][k]) ql--;
-					while (qh < 300u && (double)mn + (double)qh * (double)s < (double)hi[a][k]) qh++;
+					// (the corrections below run zero times for almost every plane; written as plain `while` loops hipcc tests four
+					// candidates per trip -- four double-precision checks before the first one is looked at, a third of what the
+					// tile collapse executed -- so the first test stands alone and the loop behind it is one that is seldom entered)
+					const double mn_d = (double)mn, s_d = (double)s, lo_d = (double)lo[a][k], hi_d = (double)hi[a][k];
+					if (ql > 0u && mn_d + (double)ql * s_d > lo_d) {
+						do ql--; while (ql > 0u && mn_d + (double)ql * s_d > lo_d);
+					}
+					if (qh < 300u && mn_d + (double)qh * s_d < hi_d) {
+						do qh++; while (qh < 300u && mn_d + (double)qh * s_d < hi_d);
+					}
 					if (qh > 255u) fits = false;
 				}
 				wl |= (ql & 255u) << (8 * k);
