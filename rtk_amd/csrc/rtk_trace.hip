@@ -950,6 +950,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			fprintf(stderr, "pool stats per 64 rays: node trips %.2f (fill %.1f, node steps %.1f lanes) leaf trips %.2f (fill %.1f) set-up trips %.2f | claim spins %.2f | clk per trip: node %.0f leaf %.0f set-up %.0f claim %.0f\n",
 				c[1] / per64, c[1] ? (double)c[4] / c[1] : 0.0, c[1] ? (double)c[8] / c[1] : 0.0, c[2] / per64, c[2] ? (double)c[5] / c[2] : 0.0, c[3] / per64, c[7] / per64,
 				c[1] ? (double)c[9] / c[1] : 0.0, c[2] ? (double)c[13] / c[2] : 0.0, c[3] ? (double)c[14] / c[3] : 0.0, (double)c[15] / (double)(c[1] + c[2] + c[3] + 1));
+			fprintf(stderr, "   (sticky form: node trips %.2f with %.1f stepping of %.1f kept rays; leaf trips %.2f fill %.1f; set-up %.2f; idle spins %.2f; top-ups tried %.2f got %.2f rays %.1f per 64 rays)\n",
+				c[1] / per64, c[1] ? (double)c[4] / c[1] : 0.0, c[1] ? (double)c[8] / c[1] : 0.0, c[2] / per64, c[2] ? (double)c[5] / c[2] : 0.0, c[3] / per64, c[7] / per64, c[9] / per64, c[13] / per64, c[14] / per64);
 			fprintf(stderr, "   lost claims per trip %.2f | node trip clk: slot %.0f, state + pop %.0f, node step %.0f, write-back %.0f, pushes %.0f\n", (double)c[0] / (double)(c[1] + c[2] + c[3] + 1),
 				(double)c[10] / c[1], (double)c[11] / c[1], (double)c[24] / c[1], ((double)c[9] - c[10] - c[11] - c[24] - c[25]) / c[1], (double)c[25] / c[1]);
 			(void)hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream);

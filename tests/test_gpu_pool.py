@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 N = (1 << 19) + 37          # above the pool's minimum batch (2^18), not a multiple of 64
 
 
+@pytest.fixture(autouse=True, params=["sticky", "queued"])
+def pool_form(request, monkeypatch):
+    """Both forms of the pool kernel: rays that stay in their lane while they are in node state (default), and every ray
+    through the queues on every trip (RTK_AMD_POOL_STICKY=0)."""
+    monkeypatch.setenv("RTK_AMD_POOL_STICKY", "1" if request.param == "sticky" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def scene(api):
     tris = synth.triangle_soup(200_000, 0.03, 7)
