@@ -181,8 +181,11 @@ def other_workload(kind, steps, warmup, frame=4096):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 100 timed steps behind 20 warm-up steps (0.12 s in all for the 1 ms frame of the default workload). The clocks of an
+    # idle MI355X take ~15 frames to come up (scripts/steps_probe.py: 1.11, 1.08, 1.07, ... 0.99 ms per frame from a cold start), so a
+    # handful of steps measures the ramp, not the rate
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="coherent", choices=["coherent", "incoherent", "shadow"])
     ap.add_argument("--bvh", default="device", choices=["device", "oracle-blob", "cpu-sah"],
                     help="device = GPU LBVH build (product path); oracle-blob = upload a blob built by the CPU oracle (debug only)")

@@ -13,7 +13,7 @@ for n in 1000000 10000000; do bash scripts/profile_build.sh $n > gpurun_out/r03_
 gcc -O2 -o examples/host_latency examples/host_latency.c -Iinclude -Lrtk_amd -lrtk_amd -lpthread -Wl,-rpath,$PWD/rtk_amd 2>/dev/null && timeout -k 10 200 ./examples/host_latency > gpurun_out/r03_c_host_latency.log 2>&1; echo "c host rc=$?"; tail -6 gpurun_out/r03_c_host_latency.log
 timeout -k 10 400 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err; echo "bench default rc=$?"
 for wl in coherent incoherent shadow; do
-  timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-other-workloads --workload $wl > gpurun_out/r03_bench_$wl.json 2> gpurun_out/r03_bench_$wl.err; echo "bench $wl rc=$?"
+  timeout -k 10 400 python bench.py --no-other-workloads --workload $wl > gpurun_out/r03_bench_$wl.json 2> gpurun_out/r03_bench_$wl.err; echo "bench $wl rc=$?"
   python3 -c "
 import json
 d=json.loads(open('gpurun_out/r03_bench_$wl.json').read().strip().splitlines()[-1])
