@@ -644,7 +644,7 @@ def main():
         out["other_workloads"] = {}
         for kind in ("incoherent", "shadow"):
             try:
-                out["other_workloads"][kind] = other_workload(kind, steps=max(3, min(args.steps, 10)), warmup=2)
+                out["other_workloads"][kind] = other_workload(kind, steps=max(3, min(args.steps, 20)), warmup=5)
             except Exception as e:      # the headline line must not die with an extra
                 out["other_workloads"][kind] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
