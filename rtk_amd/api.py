@@ -22,7 +22,6 @@ RTK_TRACE_NO_PACKET = 2
 RTK_TRACE_SORT_RAYS = 4
 RTK_TRACE_EXACT_NODES = 8
 RTK_TRACE_NO_ASM = 16
-RTK_TRACE_POOL = 32
 
 
 class RtkError(RuntimeError):
@@ -199,7 +198,7 @@ def to_device(a):
 
 
 def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, exact_nodes=False,
-              no_asm=False, pool=False):
+              no_asm=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
@@ -207,8 +206,6 @@ def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit
         o.flags |= RTK_TRACE_EXACT_NODES
     if no_asm:
         o.flags |= RTK_TRACE_NO_ASM
-    if pool:
-        o.flags |= RTK_TRACE_POOL
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

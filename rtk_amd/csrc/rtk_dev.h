@@ -79,7 +79,8 @@ static_assert(sizeof(DevTri) == RTK_TRI_STRIDE, "triangle record stride");
 struct DevSceneConsts {
 	float bound_abs;           // no plane of any node lies farther than this from the origin on its axis (>= 1: empty slots carry +1 / -1)
 	uint32_t qnode_misfits;    // nodes whose child boxes do not fit the 8-bit grid (non-finite extents): the scene then keeps to its exact nodes
-	uint32_t reserved[2];
+	float bound_raw;           // the same bound without the floor of 1 (the per-lane assembly kernels' slab margin is relative to it: a scene 1e-6 wide keeps a 1e-12 margin)
+	uint32_t reserved;
 };
 
 // Everything a kernel needs to know about a scene (passed by value).
@@ -126,6 +127,7 @@ struct rtk_dev_scene {
 	double big_leaf_fraction = 0.0;        // leaves of more than three triangles (uploads; device builds make ~none): the assembly packet kernel hands those tiles back
 	DevSceneConsts consts_readback = {};   // filled by the stream that ran k_quantize; read by rtk_quantize_finish after its synchronisation
 	float bound_abs = 0.0f;
+	float bound_raw = 0.0f;
 	// owned device allocations
 	std::vector<void *> allocs;
 	// per-stream launch scratch, created on first use; the mutex covers the list and the enqueue of a launch
@@ -165,7 +167,7 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
 // only_first: finish just the first so many nodes (the device build's tile collapse has finished the others itself);
 // keep_consts: the constants block is already set up (rtk_scene_consts) and holds counts that must survive.
 int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr, float bound_hint = 0.0f,
-	uint32_t only_first = 0xffffffffu, bool keep_consts = false);
+	uint32_t only_first = 0xffffffffu, bool keep_consts = false);   // (bound_hint: 0 = none; the floor of 1 is applied inside)
 int rtk_scene_consts(rtk_dev_scene *ds, hipStream_t stream);
 void rtk_quantize_finish(rtk_dev_scene *ds);   // after that stream has been synchronised
 

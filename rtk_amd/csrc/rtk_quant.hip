@@ -18,13 +18,14 @@ __global__ void k_quantize(DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *c
 	else *reinterpret_cast<uint4 *>(nodes[i].order) = make_uint4(nd.order[0], nd.order[1], nd.order[2], nd.order[3]);
 	if (i == 0u) {
 		// every box of a tree the device builds lies inside the root's (exact unions); an upload passes the bound over all nodes
-		float b = fmaxf(bound_hint, 1.0f);
+		float b = bound_hint;
 		for (int k = 0; k < 4; k++) {
 			if (nd.child[k] == RTK_REF_NONE) continue;
 			const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
 			for (int c = 0; c < 6; c++) b = (fabsf(v[c]) <= 3.0e38f) ? fmaxf(b, fabsf(v[c])) : INFINITY;   // NaN / inf planes: no bound
 		}
-		consts->bound_abs = b;
+		consts->bound_raw = b;
+		consts->bound_abs = fmaxf(b, 1.0f);
 	}
 	DevNodeQ q;
 	const bool misfit = !quantize_node(nd, q);
@@ -74,5 +75,6 @@ int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src
 void rtk_quantize_finish(rtk_dev_scene *ds)
 {
 	ds->bound_abs = ds->consts_readback.bound_abs;
+	ds->bound_raw = ds->consts_readback.bound_raw;
 	if (ds->consts_readback.qnode_misfits != 0u) ds->view.qnodes = nullptr;
 }

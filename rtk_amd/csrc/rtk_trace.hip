@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, PL_MIN_WAVES) rtk_trace_kernel(
 	const char *const qnodes = reinterpret_cast<const char *>(p.sc.qnodes);
 	const char *const tris = reinterpret_cast<const char *>(p.sc.tris);
 
-	// (a list whose length an earlier kernel of the launch wrote: the pool kernel's left-over rays)
+	// (a list whose length an earlier kernel of the launch wrote: the rays the assembly kernel, rtk_lane_hot.S, left over)
 	if (p.n_indirect) p.n = *p.n_indirect;
 	// wave-uniform ray range owned by this wave
 	unsigned long long w_next, w_end;
@@ -732,6 +732,60 @@ LaunchScratch *scratch_for(rtk_dev_scene *ds, hipStream_t stream)
 
 } // namespace
 
+// ---- the hand-written per-lane kernels: a code object of its own (rtk_lane_hot.S, assembled by the Makefile), carried in
+// this library as a byte array and loaded once per device
+#include "rtk_lane_hot_image.h"
+
+namespace {
+struct LaneModule { hipModule_t mod = nullptr; hipFunction_t fn[2] = { nullptr, nullptr }; int blocks_per_cu = 0; bool tried = false; };
+std::mutex g_lane_mutex;
+LaneModule g_lane[RTK_MAX_DEVICES];
+
+LaneModule *lane_module(int device)
+{
+	if (device < 0 || device >= RTK_MAX_DEVICES) return nullptr;
+	std::lock_guard<std::mutex> lock(g_lane_mutex);
+	LaneModule &h = g_lane[device];
+	if (!h.tried) {
+		int cur = -1;
+		if (hipGetDevice(&cur) != hipSuccess || cur != device) return nullptr;      // loaded by a thread that has this device current (asked again later)
+		h.tried = true;
+		if (hipModuleLoadData(&h.mod, rtk_lane_hot_image) != hipSuccess ||
+			hipModuleGetFunction(&h.fn[0], h.mod, "rtk_lane_hot_closest") != hipSuccess ||
+			hipModuleGetFunction(&h.fn[1], h.mod, "rtk_lane_hot_any") != hipSuccess) {
+			(void)hipGetLastError();
+			h.fn[0] = h.fn[1] = nullptr;
+		} else {
+			// 80 VGPRs, 30 KB of LDS per workgroup: five workgroups per CU
+			int nb = 0;
+			if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn[0], BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
+			static const int cap = getenv("RTK_AMD_LANE_BLOCKS") ? atoi(getenv("RTK_AMD_LANE_BLOCKS")) : 5;
+			h.blocks_per_cu = nb > cap ? cap : nb;
+		}
+	}
+	return h.fn[0] ? &h : nullptr;
+}
+} // namespace
+
+bool rtk_lane_hot_available(int device, int *blocks_per_cu)
+{
+	LaneModule *h = lane_module(device);
+	if (!h) return false;
+	if (blocks_per_cu) *blocks_per_cu = h->blocks_per_cu;
+	return true;
+}
+
+int rtk_lane_hot_launch(int device, const LnHotParams &hp_in, unsigned blocks, hipStream_t stream, bool any_hit)
+{
+	LaneModule *h = lane_module(device);
+	if (!h) { rtk_set_error("rtk_dev_trace: the assembly per-lane kernels are not loaded"); return RTK_AMD_ERR_HIP; }
+	LnHotParams hp = hp_in;
+	size_t size = sizeof(hp);
+	void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &hp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
+	RTK_HIP_CHECK(hipModuleLaunchKernel(h->fn[any_hit ? 1 : 0], blocks, 1, 1, BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
+	return RTK_AMD_OK;
+}
+
 void rtk_scratch_free(LaunchScratch *s)
 {
 	if (!s) return;
@@ -826,22 +880,20 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu);
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
-	// The ray-pool kernel (rtk_trace_pool.hip: one workgroup per CU with its rays in LDS, every wave trip on 64 rays that want the
-	// same kind of step; the rays it leaves over -- non-finite or zero components -- follow in rtk_trace_kernel) is an OPTION, not
-	// the default: on MI355X it reaches 83 % / 99 % lane use in node / triangle steps but half the rate of rtk_trace_kernel
-	// (1.42 against 2.86 Grays/s on incoherent rays: its trips are bound by their chain of LDS round trips at the 16 waves per
-	// CU the pool leaves room for). RTK_AMD_POOL=1 or RTK_TRACE_POOL ask for it on plain closest-hit / any-hit
-	// batches with compressed nodes.
-	static const int pool_default = getenv("RTK_AMD_POOL") ? atoi(getenv("RTK_AMD_POOL")) : 0;
-	static const size_t pool_min_rays = getenv("RTK_AMD_POOL_MIN_RAYS") ? (size_t)atoll(getenv("RTK_AMD_POOL_MIN_RAYS")) : (size_t)1 << 18;
-	const bool pool_asked = pool_default != 0 || (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_POOL));
-	const bool pool = pool_asked && !packet && !collect && !counted && !filtered && qn && p.dynamic && n >= pool_min_rays && n < 0xffffffc0ull &&
-		ds->stack_entries < 0xffffu && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_STATIC));
+	// Plain closest-hit / any-hit batches on compressed nodes go to the hand-written per-lane kernels (rtk_lane_hot.S); the rays
+	// they hand back (not tame, a leaf of four or more triangles, a stack deeper than the LDS column) follow in rtk_trace_kernel.
+	// Byte offsets into nodes, triangles, rays and the ray order are 32-bit and kept below 2^31 there.
+	static const int lane_asm_default = getenv("RTK_AMD_LANE_ASM") ? atoi(getenv("RTK_AMD_LANE_ASM")) : 1;
+	int lane_blocks_per_cu = 0;
+	const bool lane_hot = !packet && !collect && !counted && !filtered && qn && p.dynamic && p.image_w == 0 && lane_asm_default != 0 &&
+		RTK_TRI_STRIDE == 48 && n <= ((size_t)1 << 26) && (uint64_t)ds->view.num_nodes * 64u < 0x80000000ull &&
+		(uint64_t)ds->view.num_tris * RTK_TRI_STRIDE < 0x80000000ull && ds->bound_abs < 0x1p60f && ds->big_leaf_fraction <= 0.02 &&
+		!(opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_NO_ASM | RTK_TRACE_STATIC))) &&
+		rtk_lane_hot_available(ds->device, &lane_blocks_per_cu);
 
 	const size_t blocks_needed = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
 	size_t blocks = (p.dynamic || packet) ? (size_t)ds->num_cus * blocks_per_cu : blocks_needed;
 	if (blocks > blocks_needed) blocks = blocks_needed;
-	const size_t pool_blocks = (size_t)ds->num_cus;
 	if (blocks > 0x7fffffffu) { rtk_set_error("rtk_dev_trace: batch too large for one launch"); return RTK_AMD_ERR_BAD_ARG; }
 
 	// From here on the launch uses the scratch set of (scene, stream); the mutex is held until everything is
@@ -851,9 +903,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (!sc) return RTK_AMD_ERR_OOM;
 
 	// spill area for rays whose stack outgrows LDS
-	// (the pool kernel keeps fewer entries per ray in LDS; the rtk_trace_kernel pass behind it shares the area: its lanes x its entries fit)
-	const size_t lanes = pool ? std::max(blocks * BLOCK_THREADS, pool_blocks * (size_t)rtk_pool_slots()) : blocks * BLOCK_THREADS;
-	const size_t lds_entries = packet ? 16 : pool ? (size_t)rtk_pool_lds_stack() : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
+	const size_t lanes = blocks * BLOCK_THREADS;
+	const size_t lds_entries = packet ? 16 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
 	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
 	if (spill_cap && (sc->spill_lanes < lanes || sc->spill_entries_per_lane < spill_cap)) {
 		// an earlier launch on this stream may still be using the old area
@@ -930,7 +981,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		const size_t left_blocks = std::min<size_t>(blocks, (size_t)ds->num_cus * 2u);
 		rtk_packet_launch(p, (unsigned)left_blocks, stream, false);
 	} else if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
-	else if (pool) {
+	else if (lane_hot) {
 		if (sc->leftover_capacity < n * 2u) {           // (counted in uint32: the list holds one 8-byte word per left-over ray)
 			if (sc->d_leftover) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_leftover); }
 			sc->d_leftover = nullptr;
@@ -938,31 +989,25 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			RTK_HIP_CHECK(hipMalloc(&sc->d_leftover, n * sizeof(unsigned long long)), RTK_AMD_ERR_OOM);
 			sc->leftover_capacity = n * 2u;
 		}
-		p.pool_leftover = reinterpret_cast<unsigned long long *>(sc->d_leftover);
-		const int rc = rtk_pool_launch(p, (unsigned)pool_blocks, stream, any_hit);
+		LnHotParams hp = {};
+		hp.qnodes = p.sc.qnodes; hp.tris = p.sc.tris; hp.rays = p.rays;
+		hp.out = any_hit ? (void *)p.occluded : (void *)p.hits;
+		hp.counter = p.counter;
+		hp.leftover = reinterpret_cast<unsigned long long *>(sc->d_leftover);
+		hp.perm = p.perm;
+		hp.n = (uint32_t)n;
+		hp.refill_min = p.refill_min;
+		hp.node_exit = p.node_exit;
+		hp.bound_abs = ds->bound_raw;             // (no floor of 1: these kernels test child words, not inverted boxes)
+		size_t hot_blocks = (size_t)ds->num_cus * (size_t)lane_blocks_per_cu;
+		if (hot_blocks > blocks_needed) hot_blocks = blocks_needed;
+		const int rc = rtk_lane_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream, any_hit);
 		if (rc != RTK_AMD_OK) return rc;
-#ifdef POOL_STATS
-		{
-			unsigned long long c[32];
-			(void)hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream);
-			(void)hipStreamSynchronize(stream);
-			const double per64 = (double)n / 64.0;
-			fprintf(stderr, "pool stats per 64 rays: node trips %.2f (fill %.1f, node steps %.1f lanes) leaf trips %.2f (fill %.1f) set-up trips %.2f | claim spins %.2f | clk per trip: node %.0f leaf %.0f set-up %.0f claim %.0f\n",
-				c[1] / per64, c[1] ? (double)c[4] / c[1] : 0.0, c[1] ? (double)c[8] / c[1] : 0.0, c[2] / per64, c[2] ? (double)c[5] / c[2] : 0.0, c[3] / per64, c[7] / per64,
-				c[1] ? (double)c[9] / c[1] : 0.0, c[2] ? (double)c[13] / c[2] : 0.0, c[3] ? (double)c[14] / c[3] : 0.0, (double)c[15] / (double)(c[1] + c[2] + c[3] + 1));
-			fprintf(stderr, "   (sticky form: node trips %.2f with %.1f stepping of %.1f kept rays; leaf trips %.2f fill %.1f; set-up %.2f; idle spins %.2f; top-ups tried %.2f got %.2f rays %.1f per 64 rays)\n",
-				c[1] / per64, c[1] ? (double)c[4] / c[1] : 0.0, c[1] ? (double)c[8] / c[1] : 0.0, c[2] / per64, c[2] ? (double)c[5] / c[2] : 0.0, c[3] / per64, c[7] / per64, c[9] / per64, c[13] / per64, c[14] / per64);
-			fprintf(stderr, "   lost claims per trip %.2f | node trip clk: slot %.0f, state + pop %.0f, node step %.0f, write-back %.0f, pushes %.0f\n", (double)c[0] / (double)(c[1] + c[2] + c[3] + 1),
-				(double)c[10] / c[1], (double)c[11] / c[1], (double)c[24] / c[1], ((double)c[9] - c[10] - c[11] - c[24] - c[25]) / c[1], (double)c[25] / c[1]);
-			(void)hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream);
-		}
-#endif
 		// the rays it left over (none in most batches: a small grid that finds an empty list costs next to nothing)
 		TraceParams lp = p;
-		lp.perm = p.pool_leftover;
-		lp.n_indirect = p.counter + RTK_POOL_LEFTOVER_WORD;
+		lp.perm = hp.leftover;
+		lp.n_indirect = p.counter + RTK_LANE_LEFTOVER_WORD;
 		lp.n = 0;
-		lp.spill_stride = (uint32_t)(spill_cap ? sc->spill_lanes : 0);
 		const size_t left_blocks = std::min<size_t>(blocks, (size_t)ds->num_cus);
 		hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)left_blocks), dim3(BLOCK_THREADS), 0, stream, lp);
 	} else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);

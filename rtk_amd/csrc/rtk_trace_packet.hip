@@ -615,14 +615,14 @@ HotModule *hot_module(int device)
 	std::lock_guard<std::mutex> lock(g_hot_mutex);
 	HotModule &h = g_hot[device];
 	if (!h.tried) {
-		h.tried = true;
 		int cur = -1;
-		if (hipGetDevice(&cur) != hipSuccess || cur != device) return nullptr;      // loaded by a thread that has this device current
+		if (hipGetDevice(&cur) != hipSuccess || cur != device) return nullptr;      // loaded by a thread that has this device current (asked again later)
+		h.tried = true;
 		if (hipModuleLoadData(&h.mod, rtk_packet_hot_image) != hipSuccess || hipModuleGetFunction(&h.fn, h.mod, "rtk_packet_hot") != hipSuccess) {
 			(void)hipGetLastError();
 			h.fn = nullptr;
 		} else {
-			// 64 VGPRs, 96 SGPRs, 16 KB of LDS per workgroup: seven waves per SIMD (the occupancy query reports one more for
+			// 64 VGPRs, 96 SGPRs, 20 KB of LDS per workgroup (20 stack entries per lane): seven waves per SIMD (the occupancy query reports one more for
 			// kernels at this SGPR count on ROCm 7.2; 800 / (96 + 16) = 7)
 			int nb = 0;
 			if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;

@@ -39,8 +39,8 @@ struct TraceParams {
 	uint32_t *cand_count;          // MODE 2: how many of them are valid
 	uint32_t cand_k;
 	uint32_t tile_blocks;          // image batches: tiles are numbered block by block (8x8 tiles = 64x64 pixels), not row by row
-	unsigned long long *pool_leftover;      // pool kernel only: ray numbers it leaves to rtk_trace_kernel (rays with non-finite or zero components); count in counter[RTK_POOL_LEFTOVER_WORD]
-	const unsigned long long *n_indirect;   // rtk_trace_kernel: if set, the number of rays is read from here when the kernel starts (the list above)
+	const unsigned long long *n_indirect;   // rtk_trace_kernel: if set, the number of rays is read from here when the kernel starts (the list the assembly
+	                                        // per-lane kernel left over: `perm` then points at it, its length is counter[RTK_LANE_LEFTOVER_WORD])
 	const uint32_t *tile_list;     // packet kernel only: trace the tiles listed here (counter[RTK_LEFTOVER_COUNT_WORD] of them, dealt through
 	                               // counter[RTK_LEFTOVER_HEAD_WORD]) instead of all tiles: what the assembly kernel handed back
 };
@@ -48,8 +48,8 @@ struct TraceParams {
 // Scratch counter words of the hand-over from the assembly packet kernel (rtk_packet_hot.S) to the C++ one; cleared with the rest
 #define RTK_LEFTOVER_COUNT_WORD 10
 #define RTK_LEFTOVER_HEAD_WORD 11
-// ... and from the pool kernel (rtk_trace_pool.hip) to rtk_trace_kernel: how many rays it left over
-#define RTK_POOL_LEFTOVER_WORD 12
+// ... and from the assembly per-lane kernels (rtk_lane_hot.S) to rtk_trace_kernel: how many rays they left over
+#define RTK_LANE_LEFTOVER_WORD 12
 
 // Kernel argument of rtk_packet_hot (rtk_packet_hot.S reads these offsets)
 struct PkHotParams {
@@ -67,6 +67,22 @@ struct PkHotParams {
 	uint32_t pad;
 };
 static_assert(sizeof(PkHotParams) == 72 && offsetof(PkHotParams, num_blocks) == 48 && offsetof(PkHotParams, bound_abs) == 64, "rtk_packet_hot.S reads this layout");
+
+// Kernel argument of rtk_lane_hot_closest / rtk_lane_hot_any (rtk_lane_hot.S reads these offsets)
+struct LnHotParams {
+	const void *qnodes;            //  0  64-byte compressed nodes
+	const void *tris;              //  8
+	const rtk_ray *rays;           // 16
+	void *out;                     // 24  closest: rtk_hit_record per ray; any-hit: one byte per ray
+	unsigned long long *counter;   // 32
+	unsigned long long *leftover;  // 40  ray numbers handed to rtk_trace_kernel (8-byte words, the number in the low half)
+	const unsigned long long *perm;// 48  optional ray order (sort words, ray number in the low half)
+	uint32_t n;                    // 56
+	uint32_t refill_min;           // 60
+	uint32_t node_exit;            // 64
+	float bound_abs;               // 68  largest |plane| of the scene (DevSceneConsts::bound_raw)
+};
+static_assert(sizeof(LnHotParams) == 72 && offsetof(LnHotParams, n) == 56 && offsetof(LnHotParams, bound_abs) == 68, "rtk_lane_hot.S reads this layout");
 
 // DevTri.flags: bit 0 = last triangle of its leaf, bits 8.. = mesh index (for the mesh-mask filter)
 #define RTK_TRI_MESH_SHIFT 8
@@ -104,10 +120,9 @@ __device__ __forceinline__ unsigned long long map_index(unsigned long long i, ui
 }
 
 
-// rtk_trace_pool.hip: rays in an LDS pool, one 1024-thread workgroup per CU
-int rtk_pool_slots();          // rays a workgroup holds (its share of the spill area: slots x spill entries)
-int rtk_pool_lds_stack();      // stack entries per ray it keeps in LDS
-int rtk_pool_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool any_hit);
+// the hand-written per-lane kernels (rtk_lane_hot.S; loader in rtk_trace.hip)
+bool rtk_lane_hot_available(int device, int *blocks_per_cu);
+int rtk_lane_hot_launch(int device, const LnHotParams &hp, unsigned blocks, hipStream_t stream, bool any_hit);
 // rtk_trace_packet.hip
 int rtk_packet_occupancy(bool counted);
 void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool counted);

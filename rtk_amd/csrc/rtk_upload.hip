@@ -237,7 +237,7 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h)
 	ds->view.num_prims = (uint32_t)prim_slot.size();
 	// boxes of a blob need not nest, so the bound of |plane| the packet kernel's slab margins rest on is taken over every node;
 	// a scene with planes that are not finite (or beyond 1.7e38: their extent would not be) keeps to its exact nodes
-	float bound = 1.0f;
+	float bound = 0.0f;                    // (k_quantize applies the floor of 1 the packet kernels' empty-slot boxes need)
 	bool finite = true;
 	for (const DevNode &nd : h.nodes) {
 		for (int k = 0; k < 4; k++) {

@@ -1,0 +1,100 @@
+"""GPU tests of the hand-written per-lane kernels (rtk_amd/csrc/rtk_lane_hot.S, the default for plain closest-hit and any-hit
+batches): what they write must be what rtk_trace_kernel (C++, RTK_TRACE_NO_ASM) writes, byte for byte, in given and
+re-ordered ray order, at batch sizes that are not whole chunks, with rays they must hand back (non-finite or zero
+components, deep stacks) in the batch, and against the CPU oracle on the exported BVH."""
+import numpy as np
+import pytest
+
+from rtk_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N = (1 << 19) + 37          # not a multiple of 64
+
+
+@pytest.fixture(scope="module")
+def scene(api):
+    tris = synth.triangle_soup(200_000, 0.03, 7)
+    return tris, api.DeviceScene.build([dict(positions=tris)])
+
+
+def test_asm_equals_cpp_closest_hit(api, oracle, scene):
+    tris, ds = scene
+    rays = synth.rays_incoherent(N, seed=11)
+    asm = ds.trace(rays, full=False)
+    cpp = ds.trace(rays, opts=api.make_opts(no_asm=True), full=False)
+    assert asm.tobytes() == cpp.tobytes()
+    assert (asm["prim"] != 0xFFFFFFFF).mean() > 0.9
+    # ... and in a re-ordered ray order, with other launch parameters
+    assert ds.trace(rays, opts=api.make_opts(sort_rays=True), full=False).tobytes() == cpp.tobytes()
+    assert ds.trace(rays, opts=api.make_opts(refill_min=64, node_exit=1, blocks_per_cu=2), full=False).tobytes() == cpp.tobytes()
+    assert ds.trace(rays, opts=api.make_opts(refill_min=1, node_exit=64), full=False).tobytes() == cpp.tobytes()
+    # against the oracle on the same BVH (the exported blob), a sample
+    blob = oracle.Blob(ds.export_blob())
+    sel = np.arange(0, N, 97)
+    g_hits, g_mask = oracle.trace(blob, rays[sel])
+    g = asm[sel]
+    assert ((g["prim"] != 0xFFFFFFFF) == g_mask).all()
+    h = g_mask
+    assert (g["t"][h].view(np.uint32) == g_hits["t"][h].view(np.uint32)).all()
+    assert (g["u"][h].view(np.uint32) == g_hits["u"][h].view(np.uint32)).all()
+    assert (g["v"][h].view(np.uint32) == g_hits["v"][h].view(np.uint32)).all()
+
+
+def test_asm_equals_cpp_any_hit(api, scene):
+    tris, ds = scene
+    rays = synth.rays_shadow(N, seed=5)
+    asm = ds.trace_any(rays)
+    cpp = ds.trace_any(rays, opts=api.make_opts(no_asm=True))
+    assert (asm == cpp).all()
+    assert 0.05 < asm.mean() < 1.0
+    assert (ds.trace_any(rays, opts=api.make_opts(sort_rays=True)) == cpp).all()
+    # any-hit == "closest-hit found something"
+    assert (asm == (ds.trace(rays, full=False)["prim"] != 0xFFFFFFFF)).all()
+
+
+def test_asm_hands_untame_rays_to_the_exact_path(api, scene):
+    """Rays full of zeros, denormals, infinities and NaN intervals between ordinary ones: the assembly kernels hand them to
+    rtk_trace_kernel's exact path; every record must still be what the C++ kernel alone writes."""
+    tris, ds = scene
+    rays = synth.rays_incoherent(N, seed=12)
+    ex = synth.rays_exotic(2048, seed=9, tris=tris.reshape(-1, 3, 3))
+    rays[::257][:len(ex)] = ex[:len(rays[::257])]
+    asm = ds.trace(rays, full=False)
+    cpp = ds.trace(rays, opts=api.make_opts(no_asm=True), full=False)
+    assert asm.tobytes() == cpp.tobytes()
+    assert (ds.trace_any(rays) == ds.trace_any(rays, opts=api.make_opts(no_asm=True))).all()
+
+
+def test_asm_on_a_deep_tree(api):
+    """A scene whose LBVH is deep (triangles on a line with shrinking spacing): stacks outgrow the 15 LDS entries; those rays
+    are handed back and finished by the C++ kernel with its spill area."""
+    n = 60_000
+    k = np.arange(n, dtype=np.float64)
+    x = (1.0 - 0.9997 ** k).astype(np.float32)
+    c = np.stack([x, np.full(n, 0.5, np.float32), np.full(n, 0.5, np.float32)], axis=1)
+    off = (synth.u01(21, 0, n * 9).reshape(n, 3, 3) - np.float32(0.5)) * np.float32(0.02)
+    tris = (c[:, None, :] + off).astype(np.float32).reshape(n * 3, 3)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    rays = synth.rays_incoherent(N, seed=14)
+    asm = ds.trace(rays, full=False)
+    assert asm.tobytes() == ds.trace(rays, opts=api.make_opts(no_asm=True), full=False).tobytes()
+    assert (asm["prim"] != 0xFFFFFFFF).any()
+    assert (ds.trace_any(rays) == ds.trace_any(rays, opts=api.make_opts(no_asm=True))).all()
+
+
+def test_asm_on_far_away_and_tiny_scenes(api):
+    """Coordinates around 1e4 with 0.5 detail, and a scene 1e-6 wide: the slab margin is relative to |origin| + scene bound
+    (no floor of 1: the tiny scene must not open every box)."""
+    n = 50_000
+    for centre, size, spread in ((1.0e4, 100.0, 0.5), (0.0, 1.0e-6, 3.0e-8)):
+        base = synth.u01(8, 0, n * 3).reshape(n, 1, 3) * np.float32(size) + np.float32(centre)
+        off = (synth.u01(9, 0, n * 9).reshape(n, 3, 3) - np.float32(0.5)) * np.float32(spread)
+        tris = (base + off).astype(np.float32).reshape(-1, 3)
+        ds = api.DeviceScene.build([dict(positions=tris)])
+        rays = synth.rays_incoherent(1 << 16, seed=15)
+        rays["origin"] = rays["origin"] * np.float32(size) + np.float32(centre)
+        rays["direction"] = rays["direction"] * np.float32(size)
+        asm = ds.trace(rays, full=False)
+        assert asm.tobytes() == ds.trace(rays, opts=api.make_opts(no_asm=True), full=False).tobytes()
+        assert (asm["prim"] != 0xFFFFFFFF).mean() > 0.2
