@@ -888,7 +888,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	const bool lane_hot = !packet && !collect && !counted && !filtered && qn && p.dynamic && p.image_w == 0 && lane_asm_default != 0 &&
 		RTK_TRI_STRIDE == 48 && n <= ((size_t)1 << 26) && (uint64_t)ds->view.num_nodes * 64u < 0x80000000ull &&
 		(uint64_t)ds->view.num_tris * RTK_TRI_STRIDE < 0x80000000ull && ds->bound_abs < 0x1p60f && ds->big_leaf_fraction <= 0.02 &&
-		!(opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_NO_ASM | RTK_TRACE_STATIC))) &&
+		!(opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_NO_ASM | RTK_TRACE_STATIC))) && ds->stack_entries < 512u &&
 		rtk_lane_hot_available(ds->device, &lane_blocks_per_cu);
 
 	const size_t blocks_needed = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
@@ -903,7 +903,9 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (!sc) return RTK_AMD_ERR_OOM;
 
 	// spill area for rays whose stack outgrows LDS
-	const size_t lanes = blocks * BLOCK_THREADS;
+	size_t lane_hot_blocks = (size_t)ds->num_cus * (size_t)lane_blocks_per_cu;
+	if (lane_hot_blocks > blocks_needed) lane_hot_blocks = blocks_needed;
+	const size_t lanes = (lane_hot && lane_hot_blocks > blocks ? lane_hot_blocks : blocks) * BLOCK_THREADS;     // (one spill area serves the assembly kernel and the C++ pass behind it)
 	const size_t lds_entries = packet ? 16 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
 	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
 	if (spill_cap && (sc->spill_lanes < lanes || sc->spill_entries_per_lane < spill_cap)) {
@@ -999,10 +1001,18 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		hp.refill_min = p.refill_min;
 		hp.node_exit = p.node_exit;
 		hp.bound_abs = ds->bound_raw;             // (no floor of 1: these kernels test child words, not inverted boxes)
-		size_t hot_blocks = (size_t)ds->num_cus * (size_t)lane_blocks_per_cu;
-		if (hot_blocks > blocks_needed) hot_blocks = blocks_needed;
-		const int rc = rtk_lane_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream, any_hit);
+		hp.spill = p.spill;
+		hp.spill_stride = p.spill_stride;
+		hp.spill_cap = p.spill_cap;
+		const int rc = rtk_lane_hot_launch(ds->device, hp, (unsigned)lane_hot_blocks, stream, any_hit);
 		if (rc != RTK_AMD_OK) return rc;
+		static const int lane_stats = getenv("RTK_AMD_LANE_STATS") ? atoi(getenv("RTK_AMD_LANE_STATS")) : 0;
+		if (lane_stats) {           // (diagnostics: how many rays the assembly kernel handed back; synchronises the stream)
+			unsigned long long left = 0;
+			(void)hipMemcpyAsync(&left, p.counter + RTK_LANE_LEFTOVER_WORD, sizeof(left), hipMemcpyDeviceToHost, stream);
+			(void)hipStreamSynchronize(stream);
+			fprintf(stderr, "rtk_lane_hot: %llu of %zu rays handed back (%.3f %%)\n", left, n, 100.0 * (double)left / (double)n);
+		}
 		// the rays it left over (none in most batches: a small grid that finds an empty list costs next to nothing)
 		TraceParams lp = p;
 		lp.perm = hp.leftover;

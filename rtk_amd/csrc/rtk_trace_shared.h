@@ -81,8 +81,12 @@ struct LnHotParams {
 	uint32_t refill_min;           // 60
 	uint32_t node_exit;            // 64
 	float bound_abs;               // 68  largest |plane| of the scene (DevSceneConsts::bound_raw)
+	uint2 *spill;                  // 72  stack entries beyond a lane's LDS column: [entry][lane of the launch]
+	uint32_t spill_stride;         // 80  lanes of the launch (>= lanes of this kernel's grid)
+	uint32_t spill_cap;            // 84  entries per lane
 };
-static_assert(sizeof(LnHotParams) == 72 && offsetof(LnHotParams, n) == 56 && offsetof(LnHotParams, bound_abs) == 68, "rtk_lane_hot.S reads this layout");
+static_assert(sizeof(LnHotParams) == 88 && offsetof(LnHotParams, n) == 56 && offsetof(LnHotParams, bound_abs) == 68 && offsetof(LnHotParams, spill) == 72 &&
+	offsetof(LnHotParams, spill_cap) == 84, "rtk_lane_hot.S reads this layout");
 
 // DevTri.flags: bit 0 = last triangle of its leaf, bits 8.. = mesh index (for the mesh-mask filter)
 #define RTK_TRI_MESH_SHIFT 8

@@ -265,10 +265,14 @@ class Wave:
                 nxt = self.step(addr, op, ops, mods)
                 pc = pc + 1 if nxt is None else self.index[nxt]
 
-    def target(self, tok):
+    def target(self, tok, addr):
         if tok in self.labels:
             return self.labels[tok]
-        raise EmuError("unknown branch target %r" % tok)
+        try:                       # a branch to a local numeric label is printed as its word offset
+            imm = int(tok, 0) & 0xffff
+        except ValueError:
+            raise EmuError("unknown branch target %r" % tok)
+        return addr + 4 + 4 * (imm - 0x10000 if imm & 0x8000 else imm)
 
     def step(self, addr, op, ops, mods):
         base = re.sub(r"_e(32|64)$", "", op)
@@ -289,11 +293,11 @@ class Wave:
         if op in ("s_nop", "s_waitcnt"):
             return None
         if op == "s_branch":
-            return self.target(ops[0])
+            return self.target(ops[0], addr)
         if op.startswith("s_cbranch_"):
             cond = {"scc0": self.scc == 0, "scc1": self.scc == 1, "vccz": self.vcc == 0, "vccnz": self.vcc != 0,
                     "execz": self.exec == 0, "execnz": self.exec != 0}[op[len("s_cbranch_"):]]
-            return self.target(ops[0]) if cond else None
+            return self.target(ops[0], addr) if cond else None
         if op.startswith("s_load_dwordx") or op == "s_load_dword":
             n = int(op[len("s_load_dwordx"):]) if op != "s_load_dword" else 1
             a = g(ops[1]) + (g(ops[2]) & 0xffffffff if not ops[2].startswith("s") else g(ops[2]))

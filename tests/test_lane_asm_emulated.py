@@ -135,7 +135,7 @@ def build_bvh4(tv, leaf_max=3, seed=0):
     return qn, tr
 
 
-def run_lane_kernel(obj, any_hit, qn, tr, rays, perm=None, refill_min=8, node_exit=32, workgroups=2, bound=None):
+def run_lane_kernel(obj, any_hit, qn, tr, rays, perm=None, refill_min=8, node_exit=32, workgroups=2, bound=None, spill_cap=40):
     mem = emu.Memory()
     n = rays.shape[0]
     a_q, a_t, a_r = mem.add("qnodes", qn), mem.add("tris", tr), mem.add("rays", rays)
@@ -148,12 +148,16 @@ def run_lane_kernel(obj, any_hit, qn, tr, rays, perm=None, refill_min=8, node_ex
     a_p = mem.add("perm", perm) if perm is not None else 0
     if bound is None:
         bound = max(1.0, float(np.abs(tr["v0"]).max()), float(np.abs(tr["v1"]).max()), float(np.abs(tr["v2"]).max()))
-    karg = struct.pack("<7Q3If", a_q, a_t, a_r, a_o, a_c, a_l, a_p, n, refill_min, node_exit, bound)
-    assert len(karg) == 72
+    lanes = workgroups * 256
+    a_s = mem.add("spill", np.zeros(max(1, lanes * spill_cap), dtype=np.uint64))
+    karg = struct.pack("<7Q3IfQ2I", a_q, a_t, a_r, a_o, a_c, a_l, a_p, n, refill_min, node_exit, bound, a_s, lanes, spill_cap)
+    assert len(karg) == 88
     stats = emu.run_kernel(obj, "rtk_lane_hot_any" if any_hit else "rtk_lane_hot_closest", mem, karg, workgroups, 30720)
     res = mem.get(a_o).view(out.dtype).copy()
     counter = mem.get(a_c).view(np.uint64)
     left = mem.get(a_l).view(np.uint64)[:int(counter[LEFTOVER_WORD])].copy()
+    # the queue heads rtk_trace_kernel deals the left-over list from (first word of each queue's line) must be untouched
+    assert all(int(counter[16 + 16 * q]) == 0 for q in range(8)) and sum(int(counter[16 + 16 * q + 8]) for q in range(8)) >= (n + 63) // 64
     return res, left, stats
 
 
@@ -254,10 +258,10 @@ def test_untame_rays_and_big_leaves_are_handed_back(lane_obj, oracle):
     assert (res_a[done_a] == g_mask[done_a].astype(np.uint8)).all()
 
 
-def test_deep_stacks_are_handed_back_not_overrun(lane_obj, oracle):
-    """Triangles on a line with shrinking spacing, hit end-on: the median-split tree is balanced, so the stack stays
-    shallow here; depth is forced with a degenerate chain of nodes instead (every node: one leaf + one inner child,
-    all boxes the same), which a ray along the line must keep on its stack."""
+def test_deep_stacks_spill_and_are_not_overrun(lane_obj, oracle):
+    """Depth is forced with a degenerate chain of nodes (every node: three leaves + one inner child, all boxes the same),
+    which a ray along the line must keep on its stack: 13 levels x 3 pushes > 15 LDS entries. The entries beyond the LDS
+    column go to the spill area; with a spill area that is too small the rays are handed back, never written out of range."""
     m = 40
     tv = np.zeros((m, 3, 3), np.float32)
     for i in range(m):
@@ -292,5 +296,10 @@ def test_deep_stacks_are_handed_back_not_overrun(lane_obj, oracle):
     g_hits, g_mask = chain_oracle(oracle, used, rays)
     res, left, _ = run_lane_kernel(lane_obj, False, qn, tr, rays, bound=2.0)
     done = check_closest(res, left, g_hits, g_mask, rays)
-    # 13 levels x 3 pushes > 15 entries: these rays cannot be finished out of LDS
+    assert done.all() and g_mask.all()
+    res_a, left_a, _ = run_lane_kernel(lane_obj, True, qn, tr, rays, bound=2.0)
+    assert len(left_a) == 0 and (res_a == 1).all()
+    # 13 levels x 3 pushes - 15 entries in LDS = 24 > 10: these rays cannot be finished, and are handed back
+    res, left, _ = run_lane_kernel(lane_obj, False, qn, tr, rays, bound=2.0, spill_cap=10)
+    done = check_closest(res, left, g_hits, g_mask, rays)
     assert not done.any() and len(left) == len(rays)
