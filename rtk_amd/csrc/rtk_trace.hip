@@ -906,7 +906,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	size_t lane_hot_blocks = (size_t)ds->num_cus * (size_t)lane_blocks_per_cu;
 	if (lane_hot_blocks > blocks_needed) lane_hot_blocks = blocks_needed;
 	const size_t lanes = (lane_hot && lane_hot_blocks > blocks ? lane_hot_blocks : blocks) * BLOCK_THREADS;     // (one spill area serves the assembly kernel and the C++ pass behind it)
-	const size_t lds_entries = packet ? 16 : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
+	static const size_t lane_lds = getenv("RTK_AMD_LANE_LDS") ? (size_t)atoi(getenv("RTK_AMD_LANE_LDS")) : LDS_STACK;   // (A/B builds of rtk_lane_hot.S with fewer LDS entries)
+	const size_t lds_entries = packet ? 16 : (lane_hot && lane_lds < LDS_STACK) ? lane_lds : LDS_STACK;   // PK_LDS_STACK in rtk_trace_packet.hip
 	const size_t spill_cap = ds->stack_entries > lds_entries ? ds->stack_entries - lds_entries : 0;
 	if (spill_cap && (sc->spill_lanes < lanes || sc->spill_entries_per_lane < spill_cap)) {
 		// an earlier launch on this stream may still be using the old area
@@ -998,7 +999,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		hp.leftover = reinterpret_cast<unsigned long long *>(sc->d_leftover);
 		hp.perm = p.perm;
 		hp.n = (uint32_t)n;
-		hp.refill_min = p.refill_min;
+		// (re-swept for these kernels: refill at 16 idle lanes instead of 8 is +1 % / +2 %, profiles/r04_lane_sweep.log)
+		hp.refill_min = (opts && opts->struct_size >= 24 && opts->refill_min) ? p.refill_min : 16u;
 		hp.node_exit = p.node_exit;
 		hp.bound_abs = ds->bound_raw;             // (no floor of 1: these kernels test child words, not inverted boxes)
 		hp.spill = p.spill;
