@@ -37,6 +37,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 32, 16
+RAY_DTYPE_NP = np.dtype([("origin", "<f4", (3,)), ("direction", "<f4", (3,)), ("min_t", "<f4"), ("max_t", "<f4")])
+HIT_RECORD_NP = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<u4")])
 
 
 def log(*a):
@@ -115,7 +117,7 @@ def f32_ulps(a, b):
     return int(abs(int(np.float32(a).view(np.int32)) - int(np.float32(b).view(np.int32))))
 
 
-def other_workload(kind, steps, warmup, frame=4096):
+def other_workload(kind, steps, warmup, frame=4096, with_parity=True):
     """Compact line for one of the other BASELINE.json configs (config 3: incoherent rays on the 1M-triangle scene; config 5:
     10M-triangle GPU build + any-hit shadow rays), measured in the same process with the library's defaults: value, kernel
     time from events on the launch stream, the per-ray algorithmic bytes of the counting build, roofline fraction, and the
@@ -158,10 +160,64 @@ def other_workload(kind, steps, warmup, frame=4096):
     k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     res = d_out.cpu().numpy()
     hit_frac = float(res.astype(bool).mean()) if shadow else float((res.view(np.uint32).reshape(-1, 4)[:, 3] != 0xFFFFFFFF).mean())
+    # ---- sampled parity of the TIMED buffer against the oracle on the same BVH (the blob exported from this scene): 2^16 rays
+    parity = None
+    if with_parity:
+        try:
+            from oracle import pyoracle
+            tp = time.time()
+            sel = np.arange(0, n, max(1, n >> 16))
+            d_sel = torch.from_numpy(sel).cuda()
+            rays_h = np.ascontiguousarray(d_rays[d_sel].cpu().numpy()).view(RAY_DTYPE_NP).reshape(-1)
+            exported = pyoracle.Blob(ds.export_blob())
+            out_s = pyoracle.SpreadBuffer(len(sel) * 16)
+            orec = pyoracle.trace_records(exported, rays_h, out_s).copy()
+            out_s.free()
+            om = orec["triangle_index"] != 0xFFFFFFFF
+            if shadow:
+                # (any-hit parity = the flag equals the oracle's closest-hit boolean)
+                parity = {"rays": int(len(sel)), "occluded_flag_mismatches": int((res[sel].astype(bool) != om).sum())}
+            else:
+                g = res.view(HIT_RECORD_NP)[sel]
+                gm = g["prim"] != 0xFFFFFFFF
+                both = gm & om
+                same = both & (g["prim"] == orec["triangle_index"])
+                parity = {"rays": int(len(sel)), "hit_miss_mismatches": int((gm != om).sum()), "id_mismatches": int((both & ~same).sum()),
+                          "tuv_bit_exact_fraction": float(np.mean((g["t"][same].view(np.uint32) == orec["t"][same].view(np.uint32)) &
+                                                                  (g["u"][same].view(np.uint32) == orec["u"][same].view(np.uint32)) &
+                                                                  (g["v"][same].view(np.uint32) == orec["v"][same].view(np.uint32)))) if same.any() else 1.0}
+            parity["against"] = "the CPU oracle traversing the blob exported from this GPU-built scene, every %d-th ray of the timed batch" % max(1, n >> 16)
+            parity["seconds"] = round(time.time() - tp, 2)
+            del exported
+        except Exception as e:
+            parity = {"error": repr(e)}
+    # ---- config 5 end to end: build + re-order + trace as ONE wall-clock interval
+    end_to_end = None
+    if shadow:
+        def once(positions):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            ds2 = api.DeviceScene.build([dict(positions=positions)])
+            ds2.trace_any_device(d_rays, n, d_out, opts)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) * 1e3
+            b = ds2.info()["build_ms"]
+            ds2.free()
+            return dt, b
+        ds.free()
+        ds = None
+        e_dev = min(once(d_tris) for _ in range(3))
+        host_tris = d_tris.cpu().numpy()
+        e_host = min(once(host_tris) for _ in range(2))
+        del host_tris
+        end_to_end = {"from_device_resident_vertices_ms": round(e_dev[0], 3), "of_which_build_ms": round(e_dev[1], 3),
+                      "from_host_memory_ms": round(e_host[0], 3), "of_which_build_incl_pcie_ms": round(e_host[1], 3),
+                      "what": "wall clock around rtk_dev_scene_build + the re-ordering pre-pass + the any-hit trace of all %d rays (rays resident in HBM), best of 3 / 2" % n}
     pj, src, fresh = load_pmc_summary(kind)
     traffic = float(pj["hbm_traffic_bytes_per_launch"]) if (pj and fresh) else None
     lim = limiter_from_pmc(pj) if (pj and fresh) else None
-    ds.free()
+    if ds is not None:
+        ds.free()
     del d_rays, d_out, d_tris
     torch.cuda.empty_cache()
     from rtk_amd import api as _api
@@ -175,6 +231,8 @@ def other_workload(kind, steps, warmup, frame=4096):
             "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "triangles": round(ctr["triangles"] / n, 2)},
             "traffic": traffic, "traffic_source": src if traffic else ("none: %s was measured on other kernel code" % src if pj else None),
             "limiter": {k: v for k, v in lim.items()} if lim else None,
+            "ray_reordering_inside_the_step": bool(shadow), "kernel": ("rtk_lane_hot_any" if shadow else "rtk_lane_hot_closest") + " (hand-written gfx950 assembly) + rtk_trace_kernel on the rays it hands back",
+            "parity_vs_oracle_same_bvh": parity, "end_to_end": end_to_end,
             "setup_s": round(time.time() - t0, 1)}
 
 
@@ -372,7 +430,7 @@ def main():
         if how == "root":
             _, pending[b] = shard.gather_records_start(d_outs[b], sizes, dst=0, out=gathered[b])
         elif how == "striped":
-            _, pending[b], _ = shard.exchange_striped_start(d_outs[b], out_bytes, out=striped[b])
+            _, pending[b], _ = shard.exchange_striped_start(d_outs[b], out_bytes, out=striped[b], counts=[n] * world)
 
     def drain():
         for b in range(len(d_outs)):
@@ -455,6 +513,16 @@ def main():
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             other_modes[how] = float(t2.item())
     elapsed_no_gather = other_modes.get("none")
+    # N > 1 diagnostics: if the scaling is off, WHY -- a slow rank (kernel time per rank: min / max over the ranks of each
+    # rank's mean over the timed steps) or an exchange that is not hidden (step time with the exchange minus step time without)
+    rank_kernel = None
+    if world > 1:
+        mine = torch.tensor([float(np.mean(kernel_ms)) if kernel_ms else 0.0], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        rank_kernel = {"per_rank": [round(x, 4) for x in per_rank], "min": round(min(per_rank), 4), "max": round(max(per_rank), 4),
+                       "what": "mean over the timed steps of the traversal's time on each rank's launch stream (events around the launch), ms"}
     d_out = d_outs[(args.steps - 1) % len(d_outs)] if args.steps else d_outs[0]
 
     # ---- the result that was timed ---------------------------------------------------------
@@ -480,8 +548,10 @@ def main():
     mrays = total_rays / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    lane_asm = os.environ.get("RTK_AMD_LANE_ASM", "1") != "0" and lane_node_bytes == 64 and not args.static
     kernel_name = ("rtk_packet_hot (hand-written gfx950 assembly) + rtk_trace_packet_kernel<false> on the tiles it hands back" if packet_kernel else
-                   "rtk_trace_kernel<%d, false, false, %s>" % (1 if shadow else 0, "true" if lane_node_bytes == 64 else "false"))
+                   ("rtk_lane_hot_%s (hand-written gfx950 assembly) + " % ("any" if shadow else "closest") if lane_asm else "") +
+                   "rtk_trace_kernel<%d, false, false, %s>%s" % (1 if shadow else 0, "true" if lane_node_bytes == 64 else "false", " on the rays it hands back" if lane_asm else ""))
     out = {
         "metric": metric,
         "value": round(mrays, 2),
@@ -508,6 +578,10 @@ def main():
                    "value_without_gather_mrays_s": round(n * world * args.steps / elapsed_no_gather / 1e6, 2) if elapsed_no_gather else None,
                    "value_root_gather_mrays_s": round(n * world * args.steps / other_modes["root"] / 1e6, 2) if "root" in other_modes else None,
                    "value_striped_gather_mrays_s": round(n * world * args.steps / other_modes["striped"] / 1e6, 2) if "striped" in other_modes else None,
+                   "per_rank_kernel_ms": rank_kernel,
+                   "exposed_exchange_ms_per_step": ({how: round(((elapsed if how == mode else other_modes[how]) - elapsed_no_gather) / args.steps * 1e3, 4)
+                                                     for how in ("striped", "root") if (how == mode or how in other_modes)}
+                                                    if (world > 1 and elapsed_no_gather) else None),
                    "launch": "static" if args.static else "persistent",
                    "ray_order": "RTK_TRACE_SORT_RAYS: re-ordered by origin cell inside every timed step" if args.sort_rays else "as given",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
@@ -563,28 +637,39 @@ def main():
         except AttributeError:
             all_cores = os.cpu_count() or 1
         all_cores = max(1, min(all_cores, pyoracle.lib().ora_max_threads()))
-        # bounded sample: every k-th ray of the same batch (a prefix would be all top-of-frame misses)
+        # bounded sample: every k-th ray of the same batch (a prefix would be all top-of-frame misses).
+        # The timed calls write 16-byte records (what the GPU writes) into a buffer that was allocated and touched beforehand;
+        # blob, rays and output live in memory whose pages the worker threads first-touched round robin (a multi-socket host:
+        # not all on one memory controller). Round 3's figures (46.6 Mrays/s on 16 threads, 33.4 on 128) timed the first touch
+        # of 1.1 GB of 68-byte rtk_hit output inside the call, handed out in dynamic chunks of 64 rays.
+        blob_s = pyoracle.SpreadBuffer(oracle_blob.size, oracle_blob, threads=all_cores)
         probe_sel = np.arange(0, n, max(1, n >> 17))
+        probe_rays = np.ascontiguousarray(rays[probe_sel])
+        probe_out = pyoracle.SpreadBuffer(len(probe_sel) * 16, threads=all_cores)
+        pyoracle.trace_records(blob_s, probe_rays[:4096], probe_out, threads=all_cores)      # spins the thread pool up
         t0 = time.time()
-        pyoracle.trace(oracle_blob, rays[probe_sel], threads=threads)
+        pyoracle.trace_records(blob_s, probe_rays, probe_out, threads=threads)
         rate = len(probe_sel) / max(time.time() - t0, 1e-6)
         stride = 1
         while n // stride > rate * args.cpu_seconds and stride < n:
             stride *= 2
         sel = np.arange(0, n, stride)
         sample = len(sel)
-        sample_rays = rays if stride == 1 else np.ascontiguousarray(rays[sel])
+        rays_s = pyoracle.SpreadBuffer(sample * 32, rays if stride == 1 else np.ascontiguousarray(rays[sel]), threads=all_cores)
+        sample_rays = rays_s.view(rays.dtype)[:sample]
+        out_s = pyoracle.SpreadBuffer(sample * 16, threads=all_cores)
         t0 = time.time()
-        ohits, omask = pyoracle.trace(oracle_blob, sample_rays, threads=threads)
+        rec_cpu = pyoracle.trace_records(blob_s, rays_s, out_s, threads=threads).copy()
         dt = time.time() - t0
+        ohits, omask = rec_cpu, rec_cpu["triangle_index"] != 0xFFFFFFFF
         t0 = time.time()
-        pyoracle.trace(oracle_blob, rays[probe_sel], threads=1)
+        pyoracle.trace_records(blob_s, probe_rays, probe_out, threads=1)
         rate1 = len(probe_sel) / max(time.time() - t0, 1e-6)
         # the same sample on every core this process may use ("all host cores, count stated")
         rate_all = None
         if all_cores != threads:
             t0 = time.time()
-            pyoracle.trace(oracle_blob, sample_rays, threads=all_cores)
+            pyoracle.trace_records(blob_s, rays_s, out_s, threads=all_cores)
             rate_all = sample / max(time.time() - t0, 1e-6)
 
         def parity(oh, om):
@@ -619,8 +704,10 @@ def main():
                                         "note": "pinned bit for bit by tests/golden/tiny_t.npz (real rtk.c, both leaf groupings), not by a relative tolerance"}}
 
         base = {"value": round(sample / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                "sample": "%d rays = every %d-th ray of the same batch, closest-hit on the oracle's SAH BVH4 (built in %.1fs), %d OpenMP threads; 1 thread: %.3f Mrays/s"
+                "sample": "%d rays = every %d-th ray of the same batch, closest-hit on the oracle's SAH BVH4 (built in %.1fs), %d OpenMP threads, 16-byte records into "
+                          "pre-touched memory, blob / rays / output pages first-touched round robin by the workers; 1 thread: %.3f Mrays/s"
                           % (sample, stride, t_cpu_build, threads, rate1 / 1e6),
+                "one_thread": {"value": round(rate1 / 1e6, 3), "unit": "Mrays/s", "cores": 1},
                 "host_cpus": os.cpu_count(),
                 "all_cores": {"value": round(rate_all / 1e6, 3), "cores": all_cores, "unit": "Mrays/s",
                               "what": "the same sample on every core this process may use (os.sched_getaffinity)"} if rate_all else
@@ -630,10 +717,12 @@ def main():
         # (2) the SAME BVH: the oracle traverses the blob exported from the GPU-built scene -> bit-exact
         if args.bvh == "device":
             exported = pyoracle.Blob(ds.export_blob())
-            eh, em = pyoracle.trace(exported, sample_rays, threads=threads)
-            base["parity_vs_gpu_same_bvh"] = parity(eh, em)
+            eh = pyoracle.trace_records(exported, rays_s, out_s, threads=all_cores).copy()
+            base["parity_vs_gpu_same_bvh"] = parity(eh, eh["triangle_index"] != 0xFFFFFFFF)
         else:
             base["parity_vs_gpu_same_bvh"] = base["parity_vs_gpu_oracle_bvh"]
+        for b_ in (blob_s, probe_out, rays_s, out_s):
+            b_.free()
         out["cpu_baseline"] = base
     if world == 1 and args.workload == "coherent" and args.bvh == "device" and not args.no_other_workloads and not DRY and W == 4096:
         # BASELINE.json configs 3 and 5 in the same run, so that their numbers are observed by whoever runs the default

@@ -219,6 +219,14 @@ int rtk_mgpu_trace_rays(rtk_mgpu *m, const rtk_ray *rays, size_t n, rtk_hit_reco
  * (an image-shaped shard is traced in bands of whole tile rows by the packet kernel). */
 int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_rays, const size_t *counts, rtk_hit_record *const *d_records,
 	rtk_hit_record *d_gathered, int root_index, const rtk_trace_opts *opts);
+/* The same with a STRIPED exchange instead of a gather onto one root (which is bound by that root's links: eight GPUs
+ * gathered onto one deliver ~2x one GPU): GPU j ends up with stripe j of EVERY shard in d_striped[j] (memory of GPU j),
+ * segments in shard order; stripe j of a shard of c records is rtk_amd_shard_range(c, j, R) of it, and
+ * rtk_mgpu_striped_segment(counts, R, shard, stripe, &first, &count) says where it sits in d_striped[stripe]. Every GPU
+ * sends 1/R of each piece over each of its links while the rest of its shard is still being traced. */
+int rtk_mgpu_trace_rays_device_striped(rtk_mgpu *m, const rtk_ray *const *d_rays, const size_t *counts, rtk_hit_record *const *d_records,
+	rtk_hit_record *const *d_striped, const rtk_trace_opts *opts);
+void rtk_mgpu_striped_segment(const size_t *counts, int num_shards, int shard, int stripe, size_t *first, size_t *count);
 
 /* -- host-pointer convenience (PCIe-inclusive, synchronous) --
  * Closest hits of n rays against a scene blob. hits[i] is written where the ray hit
@@ -231,9 +239,11 @@ int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_rays, const 
  * one each time, against hashes of all stripes taken at upload): another scene at the same address is noticed at
  * once, a small in-place edit within size / 4 KB lookups -- not immediately. A blob in caller-owned memory keeps its
  * device copy until rtk_amd_forget_scene is called for it. Each calling thread uses its own stream and staging
- * buffers. rtk_trace_ray / rtk_trace_ray_filter (no error channel): a failure that may pass (out of memory, a stream
- * error) returns false with rtk_amd_last_error() set; one that every later call would repeat (no usable GPU, a scene
- * that does not validate) prints the error and abort()s unless RTK_AMD_SOFT_ERRORS is set in the environment. */
+ * buffers. rtk_trace_ray / rtk_trace_ray_filter (no error channel, and `false` means "miss" to a host that knows only
+ * rtk.h): a failure is never silent -- it prints one line on stderr (rate-limited after the first eight) and sets
+ * rtk_amd_last_error(). A lone failure that may pass (out of memory, an interrupted launch) then returns false; one
+ * that every later call would repeat (no usable GPU, a scene that does not validate), or a SECOND failure in a row on
+ * the calling thread (a stream error that sticks), abort()s unless RTK_AMD_SOFT_ERRORS is set in the environment. */
 size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask);
 /* Batch form of rtk_trace_ray_filter (rtk.h:130) with a host callback: per ray the closest candidate that
  * `filter` accepts. Every candidate of a ray is offered, in increasing (t, primitive id) order (equal-t ones
@@ -243,6 +253,9 @@ size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk
 size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask,
 	rtk_filter_fn *filter, void *filter_user);
 void rtk_amd_forget_scene(const rtk_scene *scene);
+/* Test hook: the next `calls` host-pointer trace calls of the process (rtk_trace_rays and everything built on it, rtk_trace_ray
+ * included) fail the way a transient device error would. */
+void rtk_amd_test_fail_next_calls(int calls);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,9 @@ def lib():
         L.ora_validate_blob.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ora_max_threads.restype = C.c_int
+        L.ora_trace_rays_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+        L.ora_alloc_spread.restype = C.c_void_p
+        L.ora_alloc_spread.argtypes = [C.c_size_t, C.c_void_p, C.c_int]
         L.ora_trace_rays_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                             C.POINTER(Filter)]
         _lib = L
@@ -161,6 +164,42 @@ def trace(blob, rays, ties=TIES_CANONICAL, threads=None, counters=False):
     if counters:
         return hits, mask.astype(bool), ctr.as_dict()
     return hits, mask.astype(bool)
+
+
+RECORD_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("triangle_index", "<u4")])
+
+
+class SpreadBuffer:
+    """Memory whose pages the OpenMP worker threads first-touched round robin (ora_alloc_spread), optionally a copy of
+    `src` (a Blob or a numpy array): the CPU baseline's blob, rays and output live in these."""
+
+    def __init__(self, nbytes, src=None, threads=None):
+        self.size = int(nbytes)
+        sp = None
+        if src is not None:
+            sp = src.ptr if isinstance(src, Blob) else np.ascontiguousarray(src).ctypes.data
+        self.ptr = lib().ora_alloc_spread(self.size, sp, threads or default_threads())
+        if not self.ptr:
+            raise MemoryError("ora_alloc_spread")
+
+    def view(self, dtype):
+        a = np.ctypeslib.as_array((C.c_uint8 * self.size).from_address(self.ptr))
+        return a.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            lib().ora_free(self.ptr)
+            self.ptr = None
+
+
+def trace_records(blob, rays, out, ties=TIES_CANONICAL, threads=None):
+    """The timing driver of the CPU baseline: closest hits of `rays` (a RAY_DTYPE array or a SpreadBuffer holding one) as
+    16-byte records into `out` (a SpreadBuffer of n * 16 bytes, allocated and touched by the caller). Returns the record view."""
+    rp = rays.ptr if isinstance(rays, SpreadBuffer) else rays.ctypes.data
+    n = (rays.size // RAY_DTYPE.itemsize) if isinstance(rays, SpreadBuffer) else rays.shape[0]
+    assert out.size >= n * RECORD_DTYPE.itemsize
+    lib().ora_trace_rays_records(blob.ptr, rp, n, out.ptr, ties, threads or default_threads())
+    return out.view(RECORD_DTYPE)[:n]
 
 
 def trace_filtered(blob, rays, mesh_mask=None, ignore=None, after=None, callback=None, threads=None):

@@ -425,6 +425,49 @@ void ora_trace_rays(const void *blob, const rtk_ray *rays, size_t n, rtk_hit *hi
 	if (total) *total = sum;
 }
 
+/* ---- the CPU baseline's timing driver (bench.py, cpu_baseline) --------------------------------------------------
+ * The same per-ray code as ora_trace_rays; what differs is everything AROUND it that decided the earlier figures
+ * (46.6 Mrays/s on 16 threads, 33.4 on 128): the 68-byte rtk_hit output was allocated and first touched inside the timed
+ * call -- 1.1 GB of page faults under one address-space lock -- and handed out in dynamic chunks of 64. Here the output is
+ * a 16-byte record per ray (what the GPU writes) in a buffer the caller allocated and touched beforehand, rays are
+ * dealt in chunks of 1024 (16 k grabs for 2^24 rays: no contention, and a slow core -- an SMT sibling, a busy neighbour -- does not hold the others up), and the blob can be copied into memory whose pages were first touched by the worker
+ * threads round robin (ora_alloc_spread), so that on a multi-socket host it does not sit on one memory controller. */
+void ora_trace_rays_records(const void *blob, const rtk_ray *rays, size_t n, ora_record *out, int ties, int threads)
+{
+	if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+#endif
+	for (long long i = 0; i < (long long)n; i++) {
+		rtk_hit h;
+		ora_record r;
+		if (ora_trace_ray(blob, &rays[i], &h, ties, NULL)) { r.t = h.t; r.u = h.u; r.v = h.v; r.triangle_index = h.triangle_index; }
+		else { r.t = rays[i].max_t; r.u = 0.0f; r.v = 0.0f; r.triangle_index = 0xffffffffu; }
+		out[i] = r;
+	}
+}
+
+/* `size` bytes, 4096-aligned, every page first touched (zeroed) by thread (page % threads) of an OpenMP team; with
+ * src != NULL the pages are filled from there instead. Free with ora_free. */
+void *ora_alloc_spread(size_t size, const void *src, int threads)
+{
+	void *p = NULL;
+	const size_t page = 4096, bytes = align_up(size ? size : 1, page);
+	if (threads < 1) threads = 1;
+	if (posix_memalign(&p, page, bytes) != 0) return NULL;
+	const long long pages = (long long)(bytes / page);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+#endif
+	for (long long k = 0; k < pages; k++) {
+		const size_t at = (size_t)k * page;
+		const size_t len = at + page <= size ? page : (at < size ? size - at : 0);
+		if (src && len) memcpy((char *)p + at, (const char *)src + at, len);
+		if (len < page) memset((char *)p + at + len, 0, page - len);
+	}
+	return p;
+}
+
 /* Canonical ties; the filter is asked about a candidate exactly when it would become the new closest hit, so
  * the result is the closest candidate the filter accepts (the order of the questions depends on the BVH, the
  * answer does not, as long as the filter is a function of the candidate). */

@@ -92,6 +92,13 @@ int ora_validate_blob(const void *blob, size_t size, uint64_t *num_nodes, uint64
 
 int ora_max_threads(void);
 
+/* The CPU baseline's timing driver (bench.py): closest hits as 16-byte records -- t, u, v, triangle_index (0xffffffff and
+ * t = max_t for a miss; single-mesh scenes) -- into a buffer the caller allocated and touched, chunks of 1024 rays; and an
+ * allocation whose pages the worker threads first-touch round robin (optionally filled from src). */
+typedef struct ora_record { float t, u, v; uint32_t triangle_index; } ora_record;
+void ora_trace_rays_records(const void *blob, const rtk_ray *rays, size_t n, ora_record *out, int ties, int threads);
+void *ora_alloc_spread(size_t size, const void *src, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1826,11 +1826,18 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	ds->num_cus = num_cus;
 	ds->mesh_base = mesh_base;
 	bool side_busy = false;             // kernels on ws.side may still be reading the workspace
-	auto fail = [&](const char *what) -> rtk_dev_scene * {
-		rtk_set_error("device build: %s: %s", what, hipGetErrorString(hipGetLastError()));
+	// Every exit that gives the scene up joins BOTH streams first: kernels already enqueued may still read or write the
+	// persistent workspace (the next build on this device reuses it as soon as the workspace mutex is released) and the
+	// scene's own allocations (freed below).
+	auto give_up = [&]() -> rtk_dev_scene * {
+		(void)hipStreamSynchronize(bs);
 		if (side_busy) (void)hipStreamSynchronize(ws.side);
 		rtk_dev_scene_free(ds);
 		return nullptr;
+	};
+	auto fail = [&](const char *what) -> rtk_dev_scene * {
+		rtk_set_error("device build: %s: %s", what, hipGetErrorString(hipGetLastError()));
+		return give_up();
 	};
 	auto dev_alloc = [&](size_t bytes) -> char * {
 		void *p = nullptr;
@@ -1958,7 +1965,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	};
 	uint32_t total_nodes = 0, depth = 0;
 	if (tile_mode) {
-		if (rtk_scene_consts(ds, bs) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+		if (rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();             // (the callee's error text stands)
 		DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
 		uint32_t h_tail[2] = { 0u, 0u };      // { wide nodes of all tiles, deepest level }
 		for (int attempt = 0;; attempt++) {
@@ -1990,7 +1997,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 				// order words and compressed copies of the nodes above the tiles (their child words are complete only now), scene constants
 				ds->view.nodes = d_nodes_;
 				ds->view.num_nodes = total_nodes;
-				if (rtk_quantize_nodes(ds, bs, nullptr, (DevNodeQ *)(d_nodes_ + node_cap), 0.0f, top_nodes ? top_nodes : 1u, true) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+				if (rtk_quantize_nodes(ds, bs, nullptr, (DevNodeQ *)(d_nodes_ + node_cap), 0.0f, top_nodes ? top_nodes : 1u, true) != RTK_AMD_OK) return give_up();
 				break;
 			}
 			if (attempt > 0) return fail("collapse (internal error: node count changed between two runs)");
@@ -2023,7 +2030,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		ds->view.nodes = d_nodes_;
 		ds->view.num_nodes = total_nodes;
 		// compressed nodes beside the exact ones (and, if the collapse had to go through the workspace, the exact ones out of it)
-		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap)) != RTK_AMD_OK) { rtk_dev_scene_free(ds); return nullptr; }
+		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap)) != RTK_AMD_OK) return give_up();
 	}
 	ds->total_bytes += node_cap * (sizeof(DevNode) + sizeof(DevNodeQ));
 	if (hipStreamSynchronize(bs) != hipSuccess || (side_busy && hipStreamSynchronize(ws.side) != hipSuccess)) return fail("sync");   // the workspace is handed back below

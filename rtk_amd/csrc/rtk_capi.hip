@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -29,6 +30,7 @@ void rtk_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *rtk_amd_last_error(void) { return g_error; }
+
 
 extern "C" int rtk_amd_device_count(void)
 {
@@ -462,6 +464,8 @@ size_t finish_piece(rtk_dev_scene *ds, HostCtx &c, size_t n, rtk_hit *hits, uint
 	return count;
 }
 
+std::atomic<int> g_test_fail_calls{0};
+extern "C" void rtk_amd_test_fail_next_calls(int calls) { g_test_fail_calls.store(calls > 0 ? calls : 0); }
 thread_local HostCtx t_ctx2;                    // second staging set (own stream) for pipelined host-pointer batches
 const size_t PIPE_CHUNK = (size_t)1 << 15;      // rays per piece when a batch is pipelined
 
@@ -472,6 +476,10 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 	if (!scene || (!rays && n)) { rtk_set_error("rtk_trace_rays: NULL argument"); return (size_t)-1; }
 	if (n == 0) return 0;
 	t_fatal = false;
+	if (g_test_fail_calls.load(std::memory_order_relaxed) > 0 && g_test_fail_calls.fetch_sub(1) > 0) {
+		rtk_set_error("rtk_trace_rays: injected failure (rtk_amd_test_fail_next_calls)");      // tests of the per-ray calls' failure reporting
+		return (size_t)-1;
+	}
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
 	if (n < 2 * PIPE_CHUNK) {
@@ -588,6 +596,30 @@ extern "C" size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *r
 
 // ---------------------------------------------------------------------------- rtk.h: trace
 
+// What a per-ray call does when its batch of one failed. The signatures have no error channel (the reference's entry point
+// cannot fail) and `false` means "miss" to a host that only knows rtk.h, so a failure is never silent:
+//   * every failure prints one line on stderr (the first 8 of a process, then every 1024th) and sets rtk_amd_last_error();
+//   * one that every later call would repeat -- no usable GPU, a scene that does not validate -- or a SECOND failure in a row
+//     on the calling thread (a stream error that sticks looks like a transient one the first time) would turn every ray
+//     into a wrong "miss": report and stop, unless the host opted into soft failures (RTK_AMD_SOFT_ERRORS: false +
+//     rtk_amd_last_error(), still reported on stderr);
+//   * a lone failure that may pass (out of memory, an interrupted launch) returns false.
+static thread_local unsigned t_per_ray_failures = 0;
+static std::atomic<unsigned long long> g_per_ray_failures_reported{0};
+
+static bool per_ray_failure(const char *who)
+{
+	const unsigned in_a_row = ++t_per_ray_failures;
+	const unsigned long long seen = g_per_ray_failures_reported.fetch_add(1);
+	const bool fatal = rtk_last_failure_is_fatal() || in_a_row >= 2u;
+	const bool soft = getenv("RTK_AMD_SOFT_ERRORS") != nullptr;
+	if (seen < 8ull || (seen & 1023ull) == 0ull || (fatal && !soft))
+		fprintf(stderr, "%s: FAILED, not a miss (%s)%s: %s\n", who, fatal ? (in_a_row >= 2u ? "second failure in a row" : "permanent") : "transient",
+			seen >= 8ull ? " [further reports are rate-limited]" : "", g_error);
+	if (fatal && !soft) abort();
+	return false;
+}
+
 // reference rtk.h:129 / rtk.c:543-577 -- a batch of one on the GPU: one small copy up, two launches, one
 // copy down on the calling thread's own stream, no allocation in steady state. Safe from any number of
 // threads on one scene. A GPU round trip per ray stays orders of magnitude slower than the batch calls;
@@ -598,15 +630,8 @@ extern "C" bool rtk_trace_ray(const rtk_scene *scene, const rtk_ray *ray, rtk_hi
 	rtk_hit h;
 	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray: NULL argument"); return false; }
 	const size_t r = rtk_trace_rays(scene, ray, 1, &h, &m);
-	if (r == (size_t)-1) {
-		// The signature has no error channel. A failure that may pass (out of memory, a stream error) returns false with
-		// rtk_amd_last_error() set; one that every later call would repeat -- no usable GPU, a scene that does not validate --
-		// would turn every ray into a silent "miss", a wrong answer rather than an error: report and stop, unless the host
-		// opted into soft failures (RTK_AMD_SOFT_ERRORS: false + rtk_amd_last_error() there too).
-		if (!rtk_last_failure_is_fatal() || getenv("RTK_AMD_SOFT_ERRORS")) return false;
-		fprintf(stderr, "rtk_trace_ray: %s\n", g_error);
-		abort();
-	}
+	if (r == (size_t)-1) return per_ray_failure("rtk_trace_ray");
+	t_per_ray_failures = 0;
 	if (m) *hit = h;
 	return m != 0;
 }
@@ -620,11 +645,8 @@ extern "C" bool rtk_trace_ray_filter(const rtk_scene *scene, const rtk_ray *ray,
 	uint8_t m = 0;
 	rtk_hit h;
 	const size_t r = rtk_trace_rays_filter(scene, ray, 1, &h, &m, filter, filter_user);
-	if (r == (size_t)-1) {
-		if (!rtk_last_failure_is_fatal() || getenv("RTK_AMD_SOFT_ERRORS")) return false;      // (see rtk_trace_ray)
-		fprintf(stderr, "rtk_trace_ray_filter: %s\n", g_error);
-		abort();
-	}
+	if (r == (size_t)-1) return per_ray_failure("rtk_trace_ray_filter");
+	t_per_ray_failures = 0;
 	if (m) *hit = h;
 	return m != 0;
 }

@@ -10,7 +10,12 @@
 //     mesh each sender has its own link into the root, so nothing is relayed and no ring is formed.
 //     A shard is traced in pieces and each piece's records leave while the next piece is being traced
 //     (a 2^24-ray shard produces 256 MB of records; one link direction carries ~77 GB/s).
-// No collective library is involved: peer copies are all a gather onto one root needs; the per-process
+//   * a gather onto ONE root is bound by that root's links (a shard's 268 MB need 3.5 ms on its one link into the root and
+//     are traced in 1.0 ms: eight GPUs gathered onto one deliver ~2x one GPU). The STRIPED form
+//     (rtk_mgpu_trace_rays_device_striped) is the answer: GPU j receives stripe j of EVERY shard, so every GPU sends
+//     1/R of each piece over each of its links and no link carries more than 1/R of a shard; the result lives striped
+//     across the GPUs (rtk_mgpu_striped_segment says where), the same layout as rtk_amd/shard.py's exchange_striped_start.
+// No collective library is involved: peer copies are all these exchanges need; the per-process
 // torch.distributed/RCCL form of the same partitioning lives in rtk_amd/shard.py for bench.py --gpus N.
 #include "rtk_dev.h"
 
@@ -163,10 +168,38 @@ extern "C" int rtk_mgpu_upload(rtk_mgpu *m, const rtk_scene *scene)
 	return replicate(m, nullptr, scene);
 }
 
-// Trace shard `i` (rays already on its GPU at d_rays, `count` of them) in pieces; each piece's records are copied to
-// dst + piece offset (host memory, or memory of device dst_device) as soon as that piece is done.
-static int trace_shard(DeviceSlot &s, const rtk_ray *d_rays, size_t count, rtk_hit_record *d_rec, rtk_hit_record *dst, int dst_device,
-	bool dst_is_host, const rtk_trace_opts *opts)
+// Where stripe `stripe` of shard `shard` lies: records [*first, *first + *count) of the buffer of GPU `stripe` (stripes of a
+// shard follow rtk_amd_shard_range(counts[shard], stripe, R); a GPU's buffer holds its stripe of shard 0, then of shard 1, ...).
+extern "C" void rtk_mgpu_striped_segment(const size_t *counts, int num_shards, int shard, int stripe, size_t *first, size_t *count)
+{
+	size_t at = 0, c = 0;
+	if (counts && num_shards > 0 && shard >= 0 && shard < num_shards && stripe >= 0 && stripe < num_shards) {
+		for (int r = 0; r < shard; r++) {
+			size_t f, k;
+			rtk_amd_shard_range(counts[r], stripe, num_shards, &f, &k);
+			at += k;
+		}
+		size_t f;
+		rtk_amd_shard_range(counts[shard], stripe, num_shards, &f, &c);
+	}
+	if (first) *first = at;
+	if (count) *count = c;
+}
+
+// One copy of `m` records from this slot's d_src to `dst`, which is host memory (dst_device < 0) or memory of device dst_device
+static int copy_records(DeviceSlot &s, rtk_hit_record *dst, int dst_device, const rtk_hit_record *d_src, size_t m)
+{
+	if (m == 0 || dst == d_src) return RTK_AMD_OK;
+	if (dst_device < 0) RTK_HIP_CHECK(hipMemcpyAsync(dst, d_src, m * sizeof(rtk_hit_record), hipMemcpyDeviceToHost, s.copy_stream), RTK_AMD_ERR_HIP);
+	else if (dst_device == s.device) RTK_HIP_CHECK(hipMemcpyAsync(dst, d_src, m * sizeof(rtk_hit_record), hipMemcpyDeviceToDevice, s.copy_stream), RTK_AMD_ERR_HIP);
+	else RTK_HIP_CHECK(hipMemcpyPeerAsync(dst, dst_device, d_src, s.device, m * sizeof(rtk_hit_record), s.copy_stream), RTK_AMD_ERR_HIP);
+	return RTK_AMD_OK;
+}
+
+// Trace a shard (rays already on its GPU at d_rays, `count` of them) in pieces; as soon as a piece is done its records
+// [at, at + m) of the shard are sent on their way by send(at, m), enqueued on the slot's copy stream.
+template <typename Send>
+static int trace_shard(DeviceSlot &s, const rtk_ray *d_rays, size_t count, rtk_hit_record *d_rec, const rtk_trace_opts *opts, Send send)
 {
 	const size_t pieces = (count + MGPU_PIECE - 1) / MGPU_PIECE;
 	while (s.events.size() < pieces) {
@@ -191,9 +224,8 @@ static int trace_shard(DeviceSlot &s, const rtk_ray *d_rays, size_t count, rtk_h
 		if (rc != RTK_AMD_OK) return rc;
 		RTK_HIP_CHECK(hipEventRecord(s.events[k], s.trace_stream), RTK_AMD_ERR_HIP);
 		RTK_HIP_CHECK(hipStreamWaitEvent(s.copy_stream, s.events[k], 0), RTK_AMD_ERR_HIP);
-		if (dst_is_host) RTK_HIP_CHECK(hipMemcpyAsync(dst + at, d_rec + at, m * sizeof(rtk_hit_record), hipMemcpyDeviceToHost, s.copy_stream), RTK_AMD_ERR_HIP);
-		else if (dst_device == s.device) { if (dst + at != d_rec + at) RTK_HIP_CHECK(hipMemcpyAsync(dst + at, d_rec + at, m * sizeof(rtk_hit_record), hipMemcpyDeviceToDevice, s.copy_stream), RTK_AMD_ERR_HIP); }
-		else RTK_HIP_CHECK(hipMemcpyPeerAsync(dst + at, dst_device, d_rec + at, s.device, m * sizeof(rtk_hit_record), s.copy_stream), RTK_AMD_ERR_HIP);
+		const int crc = send(at, m);
+		if (crc != RTK_AMD_OK) return crc;
 	}
 	return RTK_AMD_OK;
 }
@@ -247,7 +279,7 @@ extern "C" int rtk_mgpu_trace_rays(rtk_mgpu *m, const rtk_ray *rays, size_t n, r
 			shard_opts.image_height = (uint32_t)(count / opts->image_width);
 			so = &shard_opts;
 		} else if (opts && !image) so = opts;
-		return trace_shard(s, s.d_rays, count, s.d_rec, records + first, -1, true, so);
+		return trace_shard(s, s.d_rays, count, s.d_rec, so, [&](size_t at, size_t m) { return copy_records(s, records + first + at, -1, s.d_rec + at, m); });
 	});
 	const int frc = finish_all(m);
 	(void)hipSetDevice(before);
@@ -268,10 +300,54 @@ extern "C" int rtk_mgpu_trace_rays_device(rtk_mgpu *m, const rtk_ray *const *d_r
 		if (!s.scene) { rtk_set_error("rtk_mgpu_trace_rays_device: no scene"); rc = RTK_AMD_ERR_BAD_ARG; break; }
 		if (counts[r] && hipSetDevice(s.device) != hipSuccess) { rc = RTK_AMD_ERR_NO_DEVICE; break; }
 		if (counts[r]) {
-			if (d_gathered) rc = trace_shard(s, d_rays[r], counts[r], d_records[r], d_gathered + offset, m->slots[root_index].device, false, opts);
-			else rc = trace_shard(s, d_rays[r], counts[r], d_records[r], d_records[r], s.device, false, opts);
+			rtk_hit_record *const rec = d_records[r];
+			rtk_hit_record *const dst = d_gathered ? d_gathered + offset : nullptr;
+			const int dst_device = m->slots[root_index >= 0 && root_index < R ? root_index : 0].device;
+			rc = trace_shard(s, d_rays[r], counts[r], rec, opts, [&](size_t at, size_t k) { return dst ? copy_records(s, dst + at, dst_device, rec + at, k) : RTK_AMD_OK; });
 		}
 		offset += counts[r];
+	}
+	const int frc = finish_all(m);
+	(void)hipSetDevice(before);
+	return rc != RTK_AMD_OK ? rc : frc;
+}
+
+// The exchange that no single link funnels: GPU j of the context ends up with stripe j of EVERY shard (d_striped[j], a buffer
+// on GPU j of at least the sum of rtk_mgpu_striped_segment(counts, R, r, j) records), the pieces of a shard leaving in R
+// slices over R different links while the rest of the shard is still being traced. d_records[r] keeps the whole shard.
+extern "C" int rtk_mgpu_trace_rays_device_striped(rtk_mgpu *m, const rtk_ray *const *d_rays, const size_t *counts, rtk_hit_record *const *d_records,
+	rtk_hit_record *const *d_striped, const rtk_trace_opts *opts)
+{
+	if (!m || !d_rays || !counts || !d_records || !d_striped) { rtk_set_error("rtk_mgpu_trace_rays_device_striped: NULL argument"); return RTK_AMD_ERR_BAD_ARG; }
+	const int R = (int)m->slots.size();
+	int before = 0, rc = RTK_AMD_OK;
+	(void)hipGetDevice(&before);
+	for (int r = 0; r < R && rc == RTK_AMD_OK; r++) {
+		DeviceSlot &s = m->slots[r];
+		if (!s.scene) { rtk_set_error("rtk_mgpu_trace_rays_device_striped: no scene"); rc = RTK_AMD_ERR_BAD_ARG; break; }
+		if (counts[r] == 0) continue;
+		if (hipSetDevice(s.device) != hipSuccess) { rc = RTK_AMD_ERR_NO_DEVICE; break; }
+		// where each stripe of this shard begins inside the shard, and inside its destination GPU's buffer
+		std::vector<size_t> sb(R + 1), seg(R);
+		for (int j = 0; j < R; j++) {
+			size_t f, c, at, len;
+			rtk_amd_shard_range(counts[r], j, R, &f, &c);
+			rtk_mgpu_striped_segment(counts, R, r, j, &at, &len);
+			sb[j] = f; seg[j] = at;
+		}
+		sb[R] = counts[r];
+		rtk_hit_record *const rec = d_records[r];
+		rc = trace_shard(s, d_rays[r], counts[r], rec, opts, [&](size_t at, size_t k) -> int {
+			// the part of piece [at, at + k) that falls into stripe j goes to GPU j
+			for (int j = 0; j < R; j++) {
+				const size_t b = at > sb[j] ? at : sb[j], e = at + k < sb[j + 1] ? at + k : sb[j + 1];
+				if (e <= b) continue;
+				if (!d_striped[j]) { rtk_set_error("rtk_mgpu_trace_rays_device_striped: d_striped[%d] is NULL", j); return RTK_AMD_ERR_BAD_ARG; }
+				const int c = copy_records(s, d_striped[j] + seg[j] + (b - sb[j]), m->slots[j].device, rec + b, e - b);
+				if (c != RTK_AMD_OK) return c;
+			}
+			return RTK_AMD_OK;
+		});
 	}
 	const int frc = finish_all(m);
 	(void)hipSetDevice(before);

@@ -59,7 +59,25 @@ def stripe_bounds(n_records, world):
     return [shard_range(n_records, j, world) for j in range(world)]
 
 
-def exchange_striped_start(local, record_bytes, group=None, out=None):
+_equal_counts_seen = set()
+
+
+def _agreed_counts(n_rec, world, group, device):
+    """counts=None: every rank claims all shards are as long as its own. Verified once per (group, size): the ranks
+    all_gather their record counts (a few bytes; afterwards the steady-state step loop exchanges nothing)."""
+    key = (id(group), world, n_rec)
+    if key not in _equal_counts_seen:
+        mine = torch.tensor([n_rec], dtype=torch.int64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        got = [int(t.item()) for t in every]
+        if any(g != n_rec for g in got):
+            raise ValueError("exchange_striped_start: shards differ in size (%r records per rank): pass counts=shard_sizes(n, world)" % (got,))
+        _equal_counts_seen.add(key)
+    return [n_rec] * world
+
+
+def exchange_striped_start(local, record_bytes, group=None, out=None, counts=None):
     """The gather that no single link funnels: every rank ends up with stripe `rank` of EVERY shard (an all-to-all of
     record slices) instead of rank 0 ending up with everything.
 
@@ -71,7 +89,11 @@ def exchange_striped_start(local, record_bytes, group=None, out=None):
     stripe `rank` of rank r's shard, segments in rank order) -- where a distributed consumer wants it, and from where
     eight PCIe links can take it to the host at once.
 
-    `local`: this rank's records as a flat uint8 tensor (a multiple of record_bytes). Point-to-point, issued as ONE
+    `local`: this rank's records as a flat uint8 tensor (a multiple of record_bytes). `counts`: records in EVERY rank's
+    shard, in rank order (shard_sizes(n, world) for a batch cut by shard_range: shards differ by one record whenever
+    world does not divide n, and a receive posted for the wrong size hangs or truncates over RCCL); None = every shard
+    has as many records as this rank's -- checked against the other ranks' once per distinct size (an all_gather of one
+    integer), so that unequal shards without `counts` raise instead of hanging. Point-to-point, issued as ONE
     batch. Returns (out, works, segments): segments[r] = (begin, end) in bytes of rank r's contribution inside `out`;
     gather_records_wait(works) before touching `out` or overwriting `local`."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -79,8 +101,14 @@ def exchange_striped_start(local, record_bytes, group=None, out=None):
     n_rec = local.numel() // record_bytes
     if world == 1:
         return local, [], [(0, local.numel())]
-    # every rank's shard size (in records) -- the segments of `out` need them; equal shards need no exchange of sizes
-    counts = [n_rec] * world
+    if local.numel() != n_rec * record_bytes:
+        raise ValueError("exchange_striped_start: %d bytes is not a whole number of %d-byte records" % (local.numel(), record_bytes))
+    # every rank's shard size (in records): the segments of `out` and the sizes of the receives need them
+    if counts is None:
+        counts = _agreed_counts(n_rec, world, group, local.device)
+    counts = [int(c) for c in counts]
+    if len(counts) != world or counts[rank] != n_rec:
+        raise ValueError("exchange_striped_start: counts %r do not describe %d ranks with %d records on rank %d" % (counts, world, n_rec, rank))
     mine = [stripe_bounds(c, world)[rank] for c in counts]          # my stripe of rank r's shard, in records of that shard
     seg, at = [], 0
     for b, e in mine:

@@ -156,3 +156,27 @@ def test_torch_generators_equal_numpy_generators():
         t = t_fn(2048, first=123, device="cpu").numpy()
         rr = np.concatenate([r["origin"], r["direction"], r["min_t"][:, None], r["max_t"][:, None]], 1)
         assert (rr.view(np.uint32) == t.view(np.uint32)).all()
+
+
+def test_c_striped_layout_equals_the_python_exchange():
+    """rtk_mgpu_striped_segment (where the C host's striped exchange puts stripe j of shard r, rtk_mgpu.hip) is the layout of
+    rtk_amd.shard.exchange_striped_start: segments in shard order, stripes by the shard_range rule, unequal shards included."""
+    from rtk_amd import shard
+    L = api.lib()
+    f, c = C.c_size_t(), C.c_size_t()
+    for world, n in ((1, 10), (2, 1001), (3, 1000), (8, 16777216 + 5), (7, 3)):
+        counts = shard.shard_sizes(n, world)
+        arr = (C.c_size_t * world)(*counts)
+        for stripe in range(world):
+            at = 0
+            for r in range(world):
+                b, e = shard.stripe_bounds(counts[r], world)[stripe]
+                L.rtk_mgpu_striped_segment(arr, world, r, stripe, C.byref(f), C.byref(c))
+                assert (f.value, c.value) == (at, e - b)
+                at += e - b
+        # every record of every shard lands in exactly one stripe
+        total = 0
+        for stripe in range(world):
+            L.rtk_mgpu_striped_segment(arr, world, world - 1, stripe, C.byref(f), C.byref(c))
+            total += f.value + c.value
+        assert total == n

@@ -394,6 +394,35 @@ def test_single_process_multi_gpu_context_with_virtual_shards(api, oracle):
             w = ref.trace(f, opts=opts, full=False)
             assert allrec[k * len(f):(k + 1) * len(f)].tobytes() == w.tobytes()
             assert d_rec[k].cpu().numpy().tobytes() == w.tobytes()
+        # the striped exchange (no root: slot j receives stripe j of every shard); shards of unequal size that span pieces
+        counts = [len(frames[0]), len(frames[1]) - 4096 * 8 - 0, len(frames[2])]
+        counts[1] = 2048 * 1000              # a shard that is still a whole number of tile rows
+        cp2 = (C.c_size_t * 3)(*counts)
+        seg = [[None] * 3 for _ in range(3)]
+        f_, c_ = C.c_size_t(), C.c_size_t()
+        need = [0, 0, 0]
+        for j in range(3):
+            for r in range(3):
+                L.rtk_mgpu_striped_segment(cp2, 3, r, j, C.byref(f_), C.byref(c_))
+                seg[j][r] = (f_.value, c_.value)
+                need[j] = f_.value + c_.value
+        assert sum(need) == sum(counts)
+        d_str = [torch.full((need[j] * 16,), 0x5a, dtype=torch.uint8, device="cuda") for j in range(3)]
+        sp = (C.c_void_p * 3)(*[t.data_ptr() for t in d_str])
+        for t in d_rec:
+            t.zero_()
+        plain = api.make_opts()
+        torch.cuda.synchronize()
+        assert L.rtk_mgpu_trace_rays_device_striped(m, rp, cp2, op, sp, C.byref(plain)) == 0, api.last_error()
+        from rtk_amd import shard as shard_py
+        for r, f in enumerate(frames):
+            w = ref.trace(f[:counts[r]], full=False)
+            assert d_rec[r].cpu().numpy()[:counts[r] * 16].tobytes() == w.tobytes()
+            for j in range(3):
+                b, e = shard_py.stripe_bounds(counts[r], 3)[j]
+                at, ln = seg[j][r]
+                assert ln == e - b
+                assert d_str[j].cpu().numpy()[at * 16:(at + ln) * 16].tobytes() == w[b:e].tobytes()
     finally:
         L.rtk_mgpu_destroy(m)
 
@@ -594,3 +623,53 @@ def test_planes_beyond_float_range_keep_the_scene_on_exact_nodes(api, oracle):
     oh, om = oracle.trace(oracle.Blob(data), rays)
     gm = rec_default["prim"] != 0xFFFFFFFF
     assert (gm == om).all() and om.sum() > 100
+
+
+_FAIL_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from rtk_amd import api
+from rtk_amd.types import RAY_DTYPE
+tris = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+scene, keep = api.build_scene([dict(positions=tris)])
+ray = np.zeros(1, RAY_DTYPE); ray["origin"] = (0.25, 0.25, 0); ray["direction"] = (0, 0, 1); ray["max_t"] = 100.0
+assert api.trace_ray(scene, ray[0]) is not None
+api.lib().rtk_amd_test_fail_next_calls(int(sys.argv[1]))
+first = api.trace_ray(scene, ray[0])
+print("first", first is None, flush=True)
+second = api.trace_ray(scene, ray[0])
+print("second", second is None, flush=True)
+third = api.trace_ray(scene, ray[0])
+print("third", third is None, flush=True)
+"""
+
+
+def _run_failing_per_ray_calls(n_fail, soft):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RTK_AMD_SOFT_ERRORS", None)
+    if soft:
+        env["RTK_AMD_SOFT_ERRORS"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", _FAIL_SNIPPET % root, str(n_fail)], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_a_failed_per_ray_call_is_reported_not_passed_off_as_a_miss(api):
+    """rtk_trace_ray has no error channel and `false` means "miss": a failure prints a diagnostic; one that passes returns
+    false once, two in a row stop the process (unless the host opted into soft failures)."""
+    # one injected failure: reported on stderr, false once, then the real hit again
+    p = _run_failing_per_ray_calls(1, soft=False)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "first True" in p.stdout and "second False" in p.stdout and "third False" in p.stdout
+    assert "rtk_trace_ray: FAILED, not a miss (transient)" in p.stderr and "injected failure" in p.stderr
+    # two in a row: the second one is fatal
+    p = _run_failing_per_ray_calls(2, soft=False)
+    assert p.returncode != 0 and "first True" in p.stdout and "second" not in p.stdout
+    assert "second failure in a row" in p.stderr
+    # ... unless the host handles failures itself: false both times, both reported, the process lives
+    p = _run_failing_per_ray_calls(2, soft=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "first True" in p.stdout and "second True" in p.stdout and "third False" in p.stdout
+    assert p.stderr.count("FAILED, not a miss") == 2

@@ -124,6 +124,49 @@ def _striped_worker(rank, world, port, n, out_path):
     dist.destroy_process_group()
 
 
+def _striped_unequal_worker(rank, world, port, n, out_path):
+    """A batch of n records cut by shard_range over `world` ranks that do not divide it: shards differ by one record."""
+    sys.path.insert(0, ROOT)
+    from rtk_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = np.zeros((n, 4), np.uint32)
+    full[:, 0] = np.arange(n)
+    full[:, 1] = np.arange(n) * 7 + 1
+    counts = shard.shard_sizes(n, world)
+    b, e = shard.shard_range(n, rank, world)
+    local = torch.from_numpy(full[b:e].view(np.uint8).reshape(-1).copy())
+    ok = True
+    # without the counts the ranks find out that their shards differ and raise -- all of them, nobody is left waiting
+    try:
+        shard.exchange_striped_start(local, 16)
+        ok = False
+    except ValueError:
+        pass
+    out, works, seg = shard.exchange_striped_start(local, 16, counts=counts)
+    shard.gather_records_wait(works)
+    got = out.numpy().view(np.uint32).reshape(-1, 4)
+    at = 0
+    for r in range(world):
+        rb, _ = shard.shard_range(n, r, world)
+        sb, se = shard.stripe_bounds(counts[r], world)[rank]
+        ok = ok and seg[r] == (at * 16, (at + se - sb) * 16) and (got[at:at + se - sb] == full[rb + sb:rb + se]).all()
+        at += se - sb
+    ok = ok and at == len(got)
+    dist.barrier()
+    open(out_path + str(rank), "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_striped_exchange_unequal_shards(tmp_path):
+    """1000 records over 3 ranks (334 / 333 / 333 by shard_range): receives are sized from the SENDER's shard."""
+    assert len(set(__import__("rtk_amd.shard", fromlist=["x"]).shard_sizes(1000, 3))) > 1
+    out = str(tmp_path / "result")
+    mp.spawn(_striped_unequal_worker, args=(3, _free_port(), 1000, out), nprocs=3, join=True)
+    assert [open(out + str(r)).read() for r in range(3)] == ["ok"] * 3
+
+
 def test_striped_exchange_three_ranks(tmp_path):
     """The exchange that replaces the gather onto one root: every rank ends up with its stripe of every shard."""
     out = str(tmp_path / "result")
@@ -148,3 +191,7 @@ def test_bench_multi_rank_plumbing_dry_run():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert "stripe" in d["config"]["gather"] and d["config"]["value_without_gather_mrays_s"] > 0 and d["config"]["value_root_gather_mrays_s"] > 0
     assert "dry-run" in d["data"]
+    # N > 1 diagnostics: kernel time per rank, and how much of the exchange is not hidden behind the next trace
+    k = d["config"]["per_rank_kernel_ms"]
+    assert len(k["per_rank"]) == 2 and k["min"] <= k["max"]
+    assert set(d["config"]["exposed_exchange_ms_per_step"]) == {"striped", "root"}
