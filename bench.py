@@ -626,6 +626,9 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of rtk.c's trace path) on this host's cores -----
     if not args.no_cpu_baseline:
+        # idle OpenMP workers sleep instead of spinning: the pool grows to every core for the all-cores figure, and on a box
+        # whose cgroup grants fewer CPUs than it shows, spinning workers would eat the quota of the timed ones
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         from oracle import pyoracle
         t0 = time.time()
         if oracle_blob is None:
@@ -637,6 +640,18 @@ def main():
         except AttributeError:
             all_cores = os.cpu_count() or 1
         all_cores = max(1, min(all_cores, pyoracle.lib().ora_max_threads()))
+        # what the container may actually USE (cgroup v2 cpu.max = "quota period"): a one-GPU box shows 128+ CPUs and grants ~16
+        cpu_quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            cpu_quota = None if q == "max" else round(float(q) / float(per), 2)
+        except Exception:
+            try:        # cgroup v1
+                q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                cpu_quota = round(q / per, 2) if q > 0 else None
+            except Exception:
+                pass
         # bounded sample: every k-th ray of the same batch (a prefix would be all top-of-frame misses).
         # The timed calls write 16-byte records (what the GPU writes) into a buffer that was allocated and touched beforehand;
         # blob, rays and output live in memory whose pages the worker threads first-touched round robin (a multi-socket host:
@@ -708,7 +723,10 @@ def main():
                           "pre-touched memory, blob / rays / output pages first-touched round robin by the workers; 1 thread: %.3f Mrays/s"
                           % (sample, stride, t_cpu_build, threads, rate1 / 1e6),
                 "one_thread": {"value": round(rate1 / 1e6, 3), "unit": "Mrays/s", "cores": 1},
-                "host_cpus": os.cpu_count(),
+                "host_cpus": os.cpu_count(), "cgroup_cpu_quota_cores": cpu_quota,
+                "scaling_note": ("the container's CPU quota is %.1f cores: more threads than that share the same CPU time, so the all-cores figure cannot "
+                                 "exceed ~%.1f x the one-thread figure" % (cpu_quota, cpu_quota)) if cpu_quota else
+                                "no cgroup CPU quota: the all-cores figure is bound by the host (memory bandwidth of the BVH gathers, SMT siblings)",
                 "all_cores": {"value": round(rate_all / 1e6, 3), "cores": all_cores, "unit": "Mrays/s",
                               "what": "the same sample on every core this process may use (os.sched_getaffinity)"} if rate_all else
                              {"value": round(sample / dt / 1e6, 3), "cores": threads, "unit": "Mrays/s", "what": "the main figure already uses every core"}}
