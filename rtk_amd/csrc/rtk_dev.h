@@ -111,6 +111,8 @@ struct LaunchScratch {
 	size_t spill_lanes = 0;
 	void *d_sort = nullptr;                     // ray reordering scratch (RTK_TRACE_SORT_RAYS), grown on demand
 	size_t sort_capacity = 0;                   // rays
+	void *d_entries = nullptr;                  // packet kernels: entry lists of the image's 64x64-pixel blocks (PkBlockEntries), grown on demand
+	size_t entries_capacity = 0;                // blocks
 	uint32_t *d_leftover = nullptr;             // tiles the assembly packet kernel hands to the C++ one, grown on demand
 	size_t leftover_capacity = 0;               // tiles
 };

@@ -793,6 +793,7 @@ void rtk_scratch_free(LaunchScratch *s)
 	if (s->d_spill) (void)hipFree(s->d_spill);
 	if (s->d_sort) (void)hipFree(s->d_sort);
 	if (s->d_leftover) (void)hipFree(s->d_leftover);
+	if (s->d_entries) (void)hipFree(s->d_entries);
 	delete s;
 }
 
@@ -958,6 +959,22 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 
 	// queue heads and visit counters start from zero; a one-block static launch uses neither
 	if (p.dynamic || packet || counted) RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	// entry points shared by the tiles of a 64x64-pixel block (rtk_packet_entries_kernel, one small launch ahead of the traversal)
+	static const int entries_default = getenv("RTK_AMD_PACKET_ENTRIES") ? atoi(getenv("RTK_AMD_PACKET_ENTRIES")) : 1;
+	static const unsigned entries_target = getenv("RTK_AMD_ENTRY_TARGET") ? (unsigned)atoi(getenv("RTK_AMD_ENTRY_TARGET")) : 20u;
+	if (packet && p.tile_blocks && entries_default != 0 && ds->bound_abs < 0x1p19f && ds->view.num_nodes != 0u &&
+		!(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_ENTRIES))) {
+		const size_t nblk = (size_t)(p.image_w >> 6) * (p.image_h >> 6);
+		if (sc->entries_capacity < nblk) {
+			if (sc->d_entries) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_entries); }
+			sc->d_entries = nullptr;
+			sc->entries_capacity = 0;
+			RTK_HIP_CHECK(hipMalloc(&sc->d_entries, nblk * sizeof(PkBlockEntries)), RTK_AMD_ERR_OOM);
+			sc->entries_capacity = nblk;
+		}
+		rtk_packet_entries_launch(p, (PkBlockEntries *)sc->d_entries, ds->bound_abs > 1.0f ? ds->bound_abs : 1.0f, entries_target, stream);
+		p.entries = (const PkBlockEntries *)sc->d_entries;
+	}
 	if (hot) {
 		const size_t tiles = n >> 6;
 		if (sc->leftover_capacity < tiles) {
@@ -974,6 +991,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		hp.blocks_per_row = p.image_w >> 6;
 		hp.bpr_magic = (uint32_t)((0x100000000ull + hp.blocks_per_row - 1u) / hp.blocks_per_row);
 		hp.bound_abs = ds->bound_abs > 1.0f ? ds->bound_abs : 1.0f;
+		hp.entries = p.entries;
 		size_t hot_blocks = (size_t)ds->num_cus * (size_t)hot_blocks_per_cu;
 		if (hot_blocks > blocks_needed) hot_blocks = blocks_needed;
 		const int rc = rtk_packet_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream);

@@ -446,13 +446,37 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 		uint32_t stack = 0;          // wave-uniform references, entry i in lane i
 		uint32_t sp = 0;             // wave-uniform
 		uint32_t top = 0;            // wave-uniform: root
+		// the block's shared entry points (PkBlockEntries), if every ray of the tile lies inside the block's beam: the tile then
+		// starts at the listed nodes, front to back, instead of at the root
+		const PkBlockEntries *ent = p.entries;
+		uint32_t ent_next = 0, ent_count = 0;      // ent_count != 0: the tile uses the list
+		if (p.entries && p.tile_blocks && wave_fast && sign_uniform) {
+			// (the tile number is wave-uniform -- one atomic or one list slot per wave --; say so, or the entry's node reference is
+			// taken for a per-lane value and cannot address a scalar load)
+			const uint32_t blk_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tile >> 6));
+			const PkBlockEntries *eb = p.entries + blk_u;
+			const float ox = L.sox, oy = L.soy, oz = L.soz;      // (permuted copies: undo by dominant axis)
+			const float o3[3] = { L.kz0 ? oz : (L.kz1 ? oy : ox), L.kz0 ? ox : (L.kz1 ? oz : oy), L.kz0 ? oy : (L.kz1 ? ox : oz) };
+			const float r3[3] = { rdx_, rdy_, rdz_ };
+			bool in = tmin_ >= __uint_as_float(eb->pad[0]);
+			for (int a = 0; a < 3; a++) in = in && o3[a] >= eb->olo[a] && o3[a] <= eb->ohi[a] && r3[a] >= eb->rlo[a] && r3[a] <= eb->rhi[a];
+			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb->count);      // (wave-uniform by construction; say so)
+			if (__builtin_amdgcn_ballot_w64(alive && !in) == 0ull && m_alive == ~0ull && cnt != 0u) { ent = eb; ent_count = cnt; }
+		}
 		// which lanes take part in the node / leaf on top: kept as the wave's 64-bit mask (scalar registers) and turned into
 		// the per-lane condition where the vector side needs it -- as a per-lane bool carried around the loop hipcc
 		// rebuilt the mask from a 0/1 vector register at every vote (two vector instructions per ballot)
 		unsigned long long live_m = m_alive;
 		bool overflow = false;       // wave-uniform: a push did not fit (corrupted scene)
+		bool done = false;
+		if (ent_count != 0u) {
+			// the first entry
+			// (at the start nothing is culled: every lane's t is its max_t)
+			top = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent->e[0].ref);
+			ent_next = 1;
+		}
 
-		for (;;) {
+		while (!done) {
 			bool pop = false;
 			if ((int32_t)top >= 0) {
 				// ---------------------------------------------------- node (wave-uniform)
@@ -577,7 +601,20 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 						: "vcc", "scc", "memory");
 					found = hit != 0u;
 				}
-				if (!found) break;
+				if (!found) {
+					// the next entry of the block's list; they are sorted by the lower bound of the entry distance, so the first one
+					// behind every lane's hit ends the tile
+					bool took = false;
+					if (ent_next < ent_count) {
+						const float tlo = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(ent->e[ent_next].tlo)));
+						live_m = __builtin_amdgcn_ballot_w64(tlo <= L.t) & m_alive;
+						top = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent->e[ent_next].ref);
+						ent_next++;
+						took = live_m != 0ull;
+					}
+					if (!took) break;
+					continue;
+				}
 				top = (uint32_t)__builtin_amdgcn_readlane((int)stack, (int)sp);
 			}
 		}
@@ -597,6 +634,163 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 			}
 		}
 	}
+}
+
+
+// ---- entry points shared by the 64 tiles of a 64x64-pixel block (PkBlockEntries, rtk_trace_shared.h) ---------------------
+// One wave per block. The beam: 64 of the block's boundary pixels give a box of origins, a box of reciprocal directions (the same
+// IEEE quotient the tiles compute) and the smallest min_t; every tile checks its own rays against these before it uses the list
+// (for a pinhole camera the boundary bounds the interior exactly; any other camera just fails the check and starts at the root).
+// The interval slab test: per axis a lower bound of the entry parameter and an upper bound of the exit parameter over the
+// corners of (origin box) x (reciprocal box) -- float subtraction and multiplication are monotone, so the bounds hold for
+// what the reference computes for any ray of the beam, rtk.c:458-470 -- widened by the packet kernels' own margin, so that
+// every child a tile's slab test admits is admitted here. The walk goes level by level until `target` nodes are on the list.
+namespace {
+struct PkBeam { float olo[3], ohi[3], rlo[3], rhi[3], m[3], tmin; uint32_t neg; };
+
+__device__ __forceinline__ bool pk_beam_child(const DevNode &nd, int k, const PkBeam &b, float &tlo)
+{
+	const float lo[3] = { nd.bx[0][k], nd.by[0][k], nd.bz[0][k] }, hi[3] = { nd.bx[1][k], nd.by[1][k], nd.bz[1][k] };
+	float n = b.tmin, f = INFINITY;
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		const bool neg = (b.neg >> a) & 1u;
+		const float pn = neg ? hi[a] : lo[a], pf = neg ? lo[a] : hi[a];
+		const float n0 = (pn - b.olo[a]) * b.rlo[a], n1 = (pn - b.olo[a]) * b.rhi[a], n2 = (pn - b.ohi[a]) * b.rlo[a], n3 = (pn - b.ohi[a]) * b.rhi[a];
+		const float f0 = (pf - b.olo[a]) * b.rlo[a], f1 = (pf - b.olo[a]) * b.rhi[a], f2 = (pf - b.ohi[a]) * b.rlo[a], f3 = (pf - b.ohi[a]) * b.rhi[a];
+		n = fmaxf(n, fminf(fminf(n0, n1), fminf(n2, n3)) - b.m[a]);
+		f = fminf(f, fmaxf(fmaxf(f0, f1), fmaxf(f2, f3)) + b.m[a]);
+	}
+	tlo = n;
+	return n <= f;
+}
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+#define PK_FRONTIER 128
+__global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *nodes, const rtk_ray *rays, uint32_t image_w, uint32_t blocks_per_row,
+	float bound_abs, uint32_t target, PkBlockEntries *out)
+{
+	__shared__ uint32_t s_ref[2][PK_FRONTIER];
+	__shared__ float s_t[2][PK_FRONTIER];
+	__shared__ uint32_t s_out_ref[PK_MAX_ENTRIES];
+	__shared__ float s_out_t[PK_MAX_ENTRIES];
+	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+	const uint32_t bx = blk % blocks_per_row, by = blk / blocks_per_row;
+	PkBeam b;
+	bool ok = true;
+	uint32_t s_and = 7u, s_or = 0u;
+	float tmin = INFINITY;
+	for (int a = 0; a < 3; a++) { b.olo[a] = INFINITY; b.ohi[a] = -INFINITY; b.rlo[a] = INFINITY; b.rhi[a] = -INFINITY; }
+	{
+		// 64 boundary pixels of the block, one per lane and ONE round of loads: sixteen per side, the corners among them (for a
+		// pinhole camera -- reciprocal directions monotone in the pixel -- the corners alone bound the block; what any other camera
+		// puts outside these bounds fails the tiles' own check and costs speed, never a hit)
+		const uint32_t side = lane >> 4, i = lane & 15u, at = (i * 63u + 7u) / 15u;
+		const uint32_t x = side == 0u ? at : (side == 1u ? at : (side == 2u ? 0u : 63u));
+		const uint32_t y = side == 0u ? 0u : (side == 1u ? 63u : at);
+		const rtk_ray r = rays[(size_t)(by * 64u + y) * image_w + bx * 64u + x];
+		const float o[3] = { r.origin.x, r.origin.y, r.origin.z }, d[3] = { r.direction.x, r.direction.y, r.direction.z };
+		uint32_t sg = 0;
+		for (int a = 0; a < 3; a++) {
+			const float rd = 1.0f / d[a];
+			ok = ok && fabsf(o[a]) < 0x1p19f && fabsf(rd) > 0x1p-100f && fabsf(rd) < 0x1p100f;      // "tame", as the tiles test it
+			b.olo[a] = o[a]; b.ohi[a] = o[a];
+			b.rlo[a] = rd; b.rhi[a] = rd;
+			sg |= (__float_as_uint(d[a]) >> 31) << a;
+		}
+		ok = ok && r.min_t == r.min_t && r.max_t == r.max_t;
+		tmin = r.min_t;
+		s_and = sg; s_or = sg;
+	}
+	for (int o = 32; o > 0; o >>= 1) { s_and &= __shfl_xor(s_and, o); s_or |= __shfl_xor(s_or, o); }
+	ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull && s_and == s_or && bound_abs < 0x1p19f;
+	for (int a = 0; a < 3; a++) {
+		b.olo[a] = wave_min(b.olo[a]); b.ohi[a] = wave_max(b.ohi[a]); b.rlo[a] = wave_min(b.rlo[a]); b.rhi[a] = wave_max(b.rhi[a]);
+		b.m[a] = 0x1p-21f * (fmaxf(fabsf(b.rlo[a]), fabsf(b.rhi[a])) * (fmaxf(fabsf(b.olo[a]), fabsf(b.ohi[a])) + bound_abs));
+	}
+	b.tmin = wave_min(tmin);
+	b.neg = s_or;
+	PkBlockEntries *e = out + blk;
+	if (lane == 0) {
+		for (int a = 0; a < 3; a++) { e->olo[a] = b.olo[a]; e->ohi[a] = b.ohi[a]; e->rlo[a] = b.rlo[a]; e->rhi[a] = b.rhi[a]; }
+		e->pad[0] = __float_as_uint(b.tmin); e->pad[1] = 0u; e->pad[2] = 0u;
+		if (!ok) e->count = 0u;
+	}
+	if (!ok) return;
+	// level by level from the root; wave-uniform counts, appends by ballot rank
+	uint32_t n_cur = 1u, n_out = 0u, cur = 0u;
+	bool over = false;
+	if (lane == 0) { s_ref[0][0] = 0u; s_t[0][0] = b.tmin; }
+	__syncthreads();
+	for (int level = 0; level < 14 && n_cur != 0u; level++) {
+		if (level > 0 && n_out + n_cur >= target) break;
+		uint32_t n_next = 0u;
+		for (uint32_t base = 0; base < n_cur; base += 64u) {
+			const bool have = base + lane < n_cur;
+			const uint32_t ref = have ? s_ref[cur][base + lane] : 0u;
+			const float t_self = have ? s_t[cur][base + lane] : 0.0f;
+			const DevNode nd = nodes[ref];
+			bool pass[4], leaf_below = false;
+			float tlo[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				tlo[k] = 0.0f;
+				pass[k] = have && nd.child[k] != RTK_REF_NONE && pk_beam_child(nd, k, b, tlo[k]);
+				leaf_below = leaf_below || (pass[k] && (nd.child[k] & RTK_REF_LEAF) != 0u);
+			}
+			// a node with a leaf among the children the beam reaches is listed itself (a listed leaf would be tested by every
+			// tile of the block); a node the beam reaches no child of is dropped
+			const bool list_self = have && leaf_below;
+			const unsigned long long below = (1ull << lane) - 1ull;
+			const unsigned long long m_out = __builtin_amdgcn_ballot_w64(list_self);
+			if (list_self) {
+				const uint32_t at = n_out + (uint32_t)__popcll(m_out & below);
+				if (at < PK_MAX_ENTRIES) { s_out_ref[at] = ref; s_out_t[at] = t_self; }
+			}
+			n_out += (uint32_t)__popcll(m_out);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const bool push = pass[k] && !list_self;
+				const unsigned long long m_next = __builtin_amdgcn_ballot_w64(push);
+				if (push) {
+					const uint32_t at = n_next + (uint32_t)__popcll(m_next & below);
+					if (at < PK_FRONTIER) { s_ref[cur ^ 1u][at] = nd.child[k]; s_t[cur ^ 1u][at] = tlo[k]; }
+				}
+				n_next += (uint32_t)__popcll(m_next);
+			}
+		}
+		over = over || n_out > PK_MAX_ENTRIES || n_next > PK_FRONTIER;
+		if (over) break;
+		__syncthreads();
+		cur ^= 1u;
+		n_cur = n_next;
+	}
+	// the nodes that were not opened are entries too
+	if (!over) {
+		for (uint32_t i = lane; i < n_cur; i += 64u) if (n_out + i < PK_MAX_ENTRIES) { s_out_ref[n_out + i] = s_ref[cur][i]; s_out_t[n_out + i] = s_t[cur][i]; }
+		n_out += n_cur;
+		over = n_out > PK_MAX_ENTRIES;
+	}
+	__syncthreads();
+	if (over) { if (lane == 0) e->count = 0u; return; }
+	// front to back by the lower bound of the entry distance (rank = entries that come before; ties by position)
+	if (lane < n_out) {
+		const float t = s_out_t[lane];
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < n_out; j++) { const float tj = s_out_t[j]; rank += (tj < t || (tj == t && j < lane)) ? 1u : 0u; }
+		e->e[rank].ref = s_out_ref[lane];
+		e->e[rank].tlo = t;
+	}
+	if (lane == 0) e->count = n_out;
+}
+} // namespace
+
+void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float bound_abs, unsigned target, hipStream_t stream)
+{
+	const uint32_t bpr = p.image_w >> 6, rows = p.image_h >> 6;
+	hipLaunchKernelGGL(rtk_packet_entries_kernel, dim3(bpr * rows), dim3(64), 0, stream, p.sc.nodes, p.rays, p.image_w, bpr, bound_abs, target, out);
 }
 
 // ---- the hand-written kernel: a code object of its own (rtk_packet_hot.S, assembled by the Makefile), carried in this

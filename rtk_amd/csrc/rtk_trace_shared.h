@@ -41,6 +41,7 @@ struct TraceParams {
 	uint32_t tile_blocks;          // image batches: tiles are numbered block by block (8x8 tiles = 64x64 pixels), not row by row
 	const unsigned long long *n_indirect;   // rtk_trace_kernel: if set, the number of rays is read from here when the kernel starts (the list the assembly
 	                                        // per-lane kernel left over: `perm` then points at it, its length is counter[RTK_LANE_LEFTOVER_WORD])
+	const struct PkBlockEntries *entries;   // packet kernels only: per 64x64-pixel block the entry points of its rays (or NULL: every tile starts at the root)
 	const uint32_t *tile_list;     // packet kernel only: trace the tiles listed here (counter[RTK_LEFTOVER_COUNT_WORD] of them, dealt through
 	                               // counter[RTK_LEFTOVER_HEAD_WORD]) instead of all tiles: what the assembly kernel handed back
 };
@@ -50,6 +51,25 @@ struct TraceParams {
 #define RTK_LEFTOVER_HEAD_WORD 11
 // ... and from the assembly per-lane kernels (rtk_lane_hot.S) to rtk_trace_kernel: how many rays they left over
 #define RTK_LANE_LEFTOVER_WORD 12
+
+// Entry points shared by the 64 tiles of a 64x64-pixel block (rtk_packet_entries_kernel, rtk_trace_packet.hip): the block's
+// rays are bounded by a box of origins and a box of reciprocal directions (one sign per axis), that BEAM is walked down the
+// top of the tree by the interval form of the slab test, and the nodes it reaches at the cut are listed front to back by a
+// lower bound of their entry distance. A tile whose rays lie inside the beam starts at these instead of at the root
+// (config 2: 26.7 wave node steps per tile instead of 34.3) and stops at the first entry that lies behind every lane's hit.
+// Every entry is an INNER node: a node with a leaf child is listed itself and not opened -- a listed leaf would cost every
+// tile of the block a triangle test whether or not any of its rays enters the leaf's box (measured: +25 % triangle tests).
+// (Listed in the order a traversal from the root reaches them, with the smallest bound of the rest for the early exit, tiles
+// visited more nodes and were slower than from the root: profiles/r04_packet_entries.log.)
+#define PK_MAX_ENTRIES 56
+struct PkBlockEntries {
+	float olo[3], ohi[3];          //  0  the beam: origins ...
+	float rlo[3], rhi[3];          // 24  ... and reciprocal directions of the block's rays
+	uint32_t count;                // 48  entries; 0 = none (rays of mixed signs, not tame, too many entries): tiles start at the root
+	uint32_t pad[3];
+	struct { uint32_t ref; float tlo; } e[PK_MAX_ENTRIES];   // 64  node reference, lower bound of the entry distance (ascending)
+};
+static_assert(sizeof(PkBlockEntries) == 512 && offsetof(PkBlockEntries, count) == 48 && offsetof(PkBlockEntries, e) == 64, "rtk_packet_hot.S reads this layout");
 
 // Kernel argument of rtk_packet_hot (rtk_packet_hot.S reads these offsets)
 struct PkHotParams {
@@ -65,8 +85,10 @@ struct PkHotParams {
 	uint32_t bpr_magic;            // 60  ceil(2^32 / blocks_per_row): block / blocks_per_row = mul_hi(block, magic)
 	float bound_abs;               // 64  max(largest |plane| of the scene, 1)
 	uint32_t pad;
+	const PkBlockEntries *entries; // 72  per block (numbered like the tiles' blocks), or NULL
 };
-static_assert(sizeof(PkHotParams) == 72 && offsetof(PkHotParams, num_blocks) == 48 && offsetof(PkHotParams, bound_abs) == 64, "rtk_packet_hot.S reads this layout");
+static_assert(sizeof(PkHotParams) == 80 && offsetof(PkHotParams, num_blocks) == 48 && offsetof(PkHotParams, bound_abs) == 64 && offsetof(PkHotParams, entries) == 72,
+	"rtk_packet_hot.S reads this layout");
 
 // Kernel argument of rtk_lane_hot_closest / rtk_lane_hot_any (rtk_lane_hot.S reads these offsets)
 struct LnHotParams {
@@ -130,6 +152,8 @@ int rtk_lane_hot_launch(int device, const LnHotParams &hp, unsigned blocks, hipS
 // rtk_trace_packet.hip
 int rtk_packet_occupancy(bool counted);
 void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream, bool counted);
+// the blocks' entry lists (p.image_w / image_h, 64x64-pixel blocks numbered row by row) into `out`, one wave per block
+void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float bound_abs, unsigned target, hipStream_t stream);
 // the hand-written kernel (rtk_packet_hot.S): can this device run it (module loads), and its launch. blocks_per_cu: resident workgroups.
 bool rtk_packet_hot_available(int device, int *blocks_per_cu);
 int rtk_packet_hot_launch(int device, const PkHotParams &hp, unsigned blocks, hipStream_t stream);

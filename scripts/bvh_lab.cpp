@@ -352,7 +352,44 @@ static bool block_slab(const std::vector<Ray> &rs, const Box &b, float &tlo) {
 	tlo = lo; return any;
 }
 
+// What a GPU pre-pass can actually compute (PK_BEAM = 1): the block's rays bounded by an origin box and a box of reciprocal
+// directions (same signs), and the interval form of the slab test -- per axis a lower bound of the entry parameter and an upper
+// bound of the exit parameter over ALL rays of the beam. A superset of the exact union above.
+static int PK_BEAM = 0;
+struct Beam { float olo[3], ohi[3], rlo[3], rhi[3]; int neg[3]; float tmin, tmax; };
+static Beam make_beam(const std::vector<Ray> &rs) {
+	Beam b; for (int a = 0; a < 3; a++) { b.olo[a] = 1e30f; b.ohi[a] = -1e30f; b.rlo[a] = 1e30f; b.rhi[a] = -1e30f; b.neg[a] = rs[0].d[a] < 0; }
+	b.tmin = 1e30f; b.tmax = -1e30f;
+	for (const Ray &r : rs) { for (int a = 0; a < 3; a++) { const float rd = 1.0f / r.d[a]; b.olo[a] = std::min(b.olo[a], r.o[a]); b.ohi[a] = std::max(b.ohi[a], r.o[a]); b.rlo[a] = std::min(b.rlo[a], rd); b.rhi[a] = std::max(b.rhi[a], rd); } b.tmin = std::min(b.tmin, r.tmin); b.tmax = std::max(b.tmax, r.tmax); }
+	return b;
+}
+static bool beam_slab(const Beam &b, const Box &bx, float &tlo) {
+	float n = b.tmin, f = b.tmax;
+	for (int a = 0; a < 3; a++) {
+		// entry plane p_n, exit plane p_f by direction sign; t = (p - o) * rd over o in [olo, ohi], rd in [rlo, rhi] (one sign)
+		const float pn = b.neg[a] ? bx.mx[a] : bx.mn[a], pf = b.neg[a] ? bx.mn[a] : bx.mx[a];
+		float lo = 1e30f, hi = -1e30f;
+		for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) { const float o = i ? b.ohi[a] : b.olo[a], rd = j ? b.rhi[a] : b.rlo[a]; lo = std::min(lo, (pn - o) * rd); hi = std::max(hi, (pf - o) * rd); }
+		n = std::max(n, lo); f = std::min(f, hi);
+	}
+	tlo = n; return n <= f;
+}
+
 static void block_entries(const std::vector<Ray> &rs, std::vector<PkEntry> &out, PkCnt &c) {
+	if (PK_BEAM) {
+		const Beam bm = make_beam(rs);
+		out.clear();
+		struct S { int ref; float tlo; }; std::vector<S> st; st.push_back({ 0, 0.f });
+		while (!st.empty()) {
+			S s = st.back(); st.pop_back();
+			if (s.ref < 0 || wdepth[s.ref] >= PK_ENTRY_DEPTH) { out.push_back({ s.ref, s.tlo }); continue; }
+			c.pre_steps++;
+			const W &w = wide[s.ref];
+			for (int k = 0; k < w.n; k++) { float tlo; if (beam_slab(bm, w.b[k], tlo)) st.push_back({ w.ref[k], tlo }); }
+		}
+		std::sort(out.begin(), out.end(), [](const PkEntry &a, const PkEntry &b) { return a.tlo < b.tlo; });
+		return;
+	}
 	// exact union over the block's rays of "enters this node" down to depth PK_ENTRY_DEPTH (what a conservative pre-pass approximates from above)
 	out.clear();
 	struct S { int ref; float tlo; }; std::vector<S> st; st.push_back({ 0, 0.f });
@@ -843,6 +880,7 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-ws")) ws_mode = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-pf")) pk_files.push_back(argv[++i]);
 		else if (!strcmp(argv[i], "-pa")) PK_ANY = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-pm")) PK_BEAM = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-norays")) skip_rays = true;
 		else if (!strcmp(argv[i], "-wne")) WS_NODE_EXIT = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-wrm")) WS_REFILL_MIN = atoi(argv[++i]);

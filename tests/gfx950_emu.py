@@ -341,6 +341,32 @@ class Wave:
             st(ops[0], r); self.scc = int(r != 0)
         elif op == "s_mul_i32":
             st(ops[0], (g(ops[1]) * g(ops[2])) & 0xffffffff)
+        elif op == "s_mul_hi_u32":
+            st(ops[0], ((g(ops[1]) & 0xffffffff) * (g(ops[2]) & 0xffffffff)) >> 32)
+        elif op == "s_lshl_b64":
+            r = (g(ops[1]) << (g(ops[2]) & 63)) & M64
+            st(ops[0], r); self.scc = int(r != 0)
+        elif op == "s_lshl4_add_u32":
+            r = ((g(ops[1]) & 0xffffffff) << 4) + (g(ops[2]) & 0xffffffff)
+            st(ops[0], r & 0xffffffff); self.scc = int(r > 0xffffffff)
+        elif op == "s_bfe_u32":
+            a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 0xffffffff
+            r = (a >> (b & 31)) & ((1 << ((b >> 16) & 0x7f)) - 1)
+            st(ops[0], r); self.scc = int(r != 0)
+        elif op == "s_bitcmp1_b32":
+            self.scc = ((g(ops[0]) & 0xffffffff) >> (g(ops[1]) & 31)) & 1
+        elif op == "s_bcnt1_i32_b32":
+            r = bin(g(ops[1]) & 0xffffffff).count("1")
+            st(ops[0], r); self.scc = int(r != 0)
+        elif op == "s_cselect_b32":
+            st(ops[0], (g(ops[1]) if self.scc else g(ops[2])) & 0xffffffff)
+        elif op == "s_cmov_b32":
+            if self.scc:
+                st(ops[0], g(ops[1]) & 0xffffffff)
+        elif op == "s_getpc_b64":
+            st(ops[0], addr + 4)
+        elif op == "s_setpc_b64":
+            return g(ops[0])
         elif op == "s_bcnt1_i32_b64":
             r = bin(g(ops[1]) & M64).count("1")
             st(ops[0], r); self.scc = int(r != 0)
@@ -471,6 +497,11 @@ class Wave:
             below = (np.uint64(1) << limit) - np.uint64(1)
             cnt = np.array([bin(int(m & b)).count("1") for m, b in zip(mask, below)], dtype=np.uint32)
             self.vset(ops[0], cnt + s(ops[2]))
+        elif op == "v_readlane_b32":
+            self.sset(ops[0], int(s(ops[1])[self.sget(ops[2]) & 63]))
+        elif op == "v_writelane_b32":
+            r = int(re.fullmatch(r"v(\d+)", ops[0]).group(1))
+            self.v[r][self.sget(ops[2]) & 63] = self.sget(ops[1]) & 0xffffffff
         elif op == "v_readfirstlane_b32":
             if self.exec == 0:
                 lane = 0

@@ -23,6 +23,8 @@ CSRC = os.path.join(HERE, "..", "rtk_amd", "csrc")
 OBJ = os.path.join(CSRC, "obj", "rtk_lane_hot.o")
 
 NODEQ = np.dtype([("org", "<f4", (3,)), ("scale", "<f4", (3,)), ("q", "<u4", (3, 2)), ("child", "<u4", (4,))])
+NODE = np.dtype([("bx", "<f4", (2, 4)), ("by", "<f4", (2, 4)), ("bz", "<f4", (2, 4)), ("child", "<u4", (4,)), ("order", "<u4", (4,))])
+assert NODE.itemsize == 128
 TRI = np.dtype([("v0", "<f4", (3,)), ("prim", "<u4"), ("v1", "<f4", (3,)), ("flags", "<u4"), ("v2", "<f4", (3,)), ("count", "<u4")])
 assert NODEQ.itemsize == 64 and TRI.itemsize == 48
 NONE = 0xFFFFFFFF
@@ -52,7 +54,28 @@ def grid_step(extent):
     return s
 
 
-def build_bvh4(tv, leaf_max=3, seed=0):
+def child_order(nd):
+    """rtk_node_finish.h child_order: per direction octant the front-to-back order of the children (a permutation and six
+    pair bits) by the centre of the child box along the octant's diagonal."""
+    order = [0, 0, 0, 0]
+    f = np.float32
+    c = [[f(nd[ax][0][k]) + f(nd[ax][1][k]) for k in range(4)] for ax in ("bx", "by", "bz")]
+    for o in range(8):
+        key = []
+        for k in range(4):
+            sv = f((-c[0][k] if o & 1 else c[0][k]) + (-c[1][k] if o & 2 else c[1][k]))
+            sv = f(sv + (-c[2][k] if o & 4 else c[2][k]))
+            key.append(np.inf if int(nd["child"][k]) == NONE else (np.inf if np.isnan(sv) else float(sv)))
+        b = {(i, j): int(key[i] <= key[j]) for i in range(4) for j in range(i + 1, 4)}
+        r = [(1 - b[0, 1]) + (1 - b[0, 2]) + (1 - b[0, 3]), b[0, 1] + (1 - b[1, 2]) + (1 - b[1, 3]), b[0, 2] + b[1, 2] + (1 - b[2, 3]), b[0, 3] + b[1, 3] + b[2, 3]]
+        word = (0 << (2 * r[0])) | (1 << (2 * r[1])) | (2 << (2 * r[2])) | (3 << (2 * r[3]))
+        pair = (1 - b[0, 1]) | ((1 - b[0, 2]) << 1) | ((1 - b[0, 3]) << 2) | ((1 - b[1, 2]) << 3) | ((1 - b[1, 3]) << 4) | ((1 - b[2, 3]) << 5)
+        word |= pair << 8
+        order[o >> 1] |= word << (16 * (o & 1))
+    return order
+
+
+def build_bvh4(tv, leaf_max=3, seed=0, want_exact=False):
     """A 4-wide tree over triangles tv [n,3,3] (median splits on the longest axis, two binary levels per node) in the
     device layout: 64-byte compressed nodes whose 8-bit boxes CONTAIN the exact ones (rtk_node_finish.h quantize_node),
     48-byte triangle records, leaves = runs of records."""
@@ -91,6 +114,11 @@ def build_bvh4(tv, leaf_max=3, seed=0):
         for p in parts:
             boxes.append((lo_t[p].min(axis=0), hi_t[p].max(axis=0)))
             child.append(emit_leaf(p) if len(p) <= leaf_max else None)
+        ex = np.zeros((), dtype=NODE)
+        for k in range(4):
+            for a, ax in enumerate(("bx", "by", "bz")):
+                ex[ax][0][k] = boxes[k][0][a] if k < len(boxes) else 1.0        # empty slot: the inverted box +1 / -1
+                ex[ax][1][k] = boxes[k][1][a] if k < len(boxes) else -1.0
         rec = np.zeros((), dtype=NODEQ)
         for a in range(3):
             mn = np.float32(min(b[0][a] for b in boxes))
@@ -124,14 +152,20 @@ def build_bvh4(tv, leaf_max=3, seed=0):
                 rec["child"][k] = child[k]
             else:
                 rec["child"][k] = make(parts[k])
+        ex["child"] = rec["child"]
+        ex["order"] = child_order(ex)
         nodes[me] = rec
+        exact[me] = ex
         return me
 
+    exact = {}
     make(np.arange(n))
     qn = np.array(nodes, dtype=NODEQ)
     tr = np.zeros(len(tris), dtype=TRI)
     for i, (a, prim, b, flags, c, cnt) in enumerate(tris):
         tr[i] = (a, prim, b, flags, c, cnt)
+    if want_exact:
+        return qn, tr, np.array([exact[i] for i in range(len(nodes))], dtype=NODE)
     return qn, tr
 
 

@@ -1,0 +1,211 @@
+"""The hand-written packet kernel (rtk_amd/csrc/rtk_packet_hot.S) run on the CPU, in tests/gfx950_emu.py, against the oracle:
+tiles that start at the root, tiles that start at their block's shared entry points (a Python port of
+rtk_packet_entries_kernel builds the lists), tiles whose rays do not fit the block's beam, and tiles it hands back.
+
+Oracle as in tests/test_lane_asm_emulated.py: rtk.c's arithmetic over a chain of one-triangle leaf blobs (double-precision
+edge functions, rtk.c:306: what the kernel uses for its leaves of fewer than four triangles), so ids and t, u, v are bit-exact.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from rtk_amd import synth
+from rtk_amd.types import HIT_RECORD_DTYPE, RAY_DTYPE
+
+from . import gfx950_emu as emu
+from .test_lane_asm_emulated import CSRC, NONE, build_bvh4, chain_oracle, oracle   # noqa: F401  (oracle: a fixture)
+
+OBJ = os.path.join(CSRC, "obj", "rtk_packet_hot.o")
+COUNTER_WORDS = 16 + 16 * 8 + 1
+ENTRIES = np.dtype([("olo", "<f4", (3,)), ("ohi", "<f4", (3,)), ("rlo", "<f4", (3,)), ("rhi", "<f4", (3,)), ("count", "<u4"), ("tmin", "<f4"),
+                    ("pad", "<u4", (2,)), ("e", [("ref", "<u4"), ("tlo", "<f4")], (56,))])
+assert ENTRIES.itemsize == 512
+W, H = 128, 64            # two 64x64-pixel blocks = 128 tiles
+
+
+@pytest.fixture(scope="module")
+def packet_obj():
+    subprocess.check_call(["make", "-s", "-C", CSRC, os.path.join(os.path.abspath(CSRC), "obj", "rtk_packet_hot.hsaco")])
+    return OBJ
+
+
+@pytest.fixture(scope="module")
+def scene():
+    tv = synth.triangle_soup(500, 0.15, seed=11).reshape(-1, 3, 3)
+    qn, tr, nodes = build_bvh4(tv, want_exact=True)
+    return tv, tr, nodes
+
+
+def camera(x0, y0, span, w=W, h=H, origin=(0.5, 0.5, -1.5)):
+    """w x h rays from one origin, directions ((x0 + span * (x + 0.5) / w), (y0 + span * (y + 0.5) / w), 1), row-major."""
+    r = np.zeros(w * h, dtype=RAY_DTYPE)
+    x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    r["origin"] = origin
+    r["direction"][:, 0] = (np.float32(x0) + np.float32(span) * (x.reshape(-1) + np.float32(0.5)) / np.float32(w))
+    r["direction"][:, 1] = (np.float32(y0) + np.float32(span) * (y.reshape(-1) + np.float32(0.5)) / np.float32(w))
+    r["direction"][:, 2] = 1.0
+    r["max_t"] = 3.0e38
+    return r
+
+
+def beam_entries(nodes, rays, w, h, bound, target=20):
+    """Python port of rtk_packet_entries_kernel: per 64x64-pixel block the beam of its boundary rays and the nodes the beam
+    reaches, level by level until `target` are listed, front to back."""
+    f = np.float32
+    bpr, rows = w // 64, h // 64
+    out = np.zeros(bpr * rows, dtype=ENTRIES)
+    img = rays.reshape(h, w)
+    with np.errstate(all="ignore"):
+        for blk in range(bpr * rows):
+            bx, by = blk % bpr, blk // bpr
+            sub = img[by * 64:by * 64 + 64, bx * 64:bx * 64 + 64]
+            at = (np.arange(16) * 63 + 7) // 15                      # sixteen pixels per side, the corners among them
+            edge = np.concatenate([sub[0, at], sub[63, at], sub[at, 0], sub[at, 63]])
+            o, d = edge["origin"], edge["direction"]
+            rd = (f(1.0) / d).astype(f)
+            e = out[blk]
+            e["olo"], e["ohi"], e["rlo"], e["rhi"] = o.min(axis=0), o.max(axis=0), rd.min(axis=0), rd.max(axis=0)
+            e["tmin"] = edge["min_t"].min()
+            neg = np.signbit(d)
+            ok = (neg.all(axis=0) | (~neg).all(axis=0)).all() and (np.abs(o) < 2.0 ** 19).all() and (np.abs(rd) > 2.0 ** -100).all() and \
+                (np.abs(rd) < 2.0 ** 100).all() and bound < 2.0 ** 19 and not np.isnan(edge["min_t"]).any() and not np.isnan(edge["max_t"]).any()
+            if not ok:
+                continue
+            neg = neg[0]
+            m = (f(2.0 ** -21) * (np.maximum(np.abs(e["rlo"]), np.abs(e["rhi"])) * (np.maximum(np.abs(e["olo"]), np.abs(e["ohi"])) + f(bound)))).astype(f)
+
+            def child(nd, k):
+                n, far = f(e["tmin"]), f(np.inf)
+                for a, ax in enumerate(("bx", "by", "bz")):
+                    lo, hi = f(nd[ax][0][k]), f(nd[ax][1][k])
+                    pn, pf = (hi, lo) if neg[a] else (lo, hi)
+                    ns = [f(f(pn - oo) * rr) for oo in (e["olo"][a], e["ohi"][a]) for rr in (e["rlo"][a], e["rhi"][a])]
+                    fs = [f(f(pf - oo) * rr) for oo in (e["olo"][a], e["ohi"][a]) for rr in (e["rlo"][a], e["rhi"][a])]
+                    n = max(n, f(min(ns) - m[a]))
+                    far = min(far, f(max(fs) + m[a]))
+                return n <= far, n
+            cur, listed, over = [(0, f(e["tmin"]))], [], False
+            for level in range(14):
+                if not cur or (level > 0 and len(listed) + len(cur) >= target):
+                    break
+                nxt = []
+                for ref, t_self in cur:
+                    nd = nodes[ref]
+                    reached = []
+                    for k in range(4):
+                        c = int(nd["child"][k])
+                        if c == NONE:
+                            continue
+                        ok_k, tlo = child(nd, k)
+                        if ok_k:
+                            reached.append((c, tlo))
+                    if any(c & 0x80000000 for c, _ in reached):
+                        listed.append((ref, t_self))         # a node with a leaf child the beam reaches is listed itself
+                    else:
+                        nxt += reached
+                over = over or len(listed) > 56 or len(nxt) > 128
+                if over:
+                    break
+                cur = nxt
+            listed += cur
+            if over or len(listed) > 56:
+                continue
+            order = sorted(range(len(listed)), key=lambda i: (listed[i][1], i))
+            e["count"] = len(listed)
+            for q, i in enumerate(order):
+                e["e"][q] = (listed[i][0], listed[i][1])
+    return out
+
+
+def run_packet_kernel(obj, nodes, tr, rays, w, h, entries=None, bound=None, workgroups=2):
+    mem = emu.Memory()
+    n = w * h
+    a_n, a_t, a_r = mem.add("nodes", nodes), mem.add("tris", tr), mem.add("rays", rays)
+    out = np.zeros(n, dtype=HIT_RECORD_DTYPE)
+    out.view(np.uint32)[:] = 0x7e7e7e7e
+    a_o = mem.add("hits", out)
+    a_c = mem.add("counter", np.zeros(COUNTER_WORDS, dtype=np.uint64))
+    a_l = mem.add("leftover", np.zeros(n // 64, dtype=np.uint32))
+    a_e = mem.add("entries", entries) if entries is not None else 0
+    if bound is None:
+        bound = max(1.0, float(np.abs(tr["v0"]).max()), float(np.abs(tr["v1"]).max()), float(np.abs(tr["v2"]).max()))
+    bpr = w // 64
+    karg = struct.pack("<6Q4IfIQ", a_n, a_t, a_r, a_o, a_c, a_l, (w // 64) * (h // 64), w, bpr, (0x100000000 + bpr - 1) // bpr, bound, 0, a_e)
+    assert len(karg) == 80
+    stats = emu.run_kernel(obj, "rtk_packet_hot", mem, karg, workgroups, 20480, max_instructions=6_000_000)
+    res = mem.get(a_o).view(HIT_RECORD_DTYPE).copy()
+    counter = mem.get(a_c).view(np.uint64)
+    left = mem.get(a_l).view(np.uint32)[:int(counter[10])].copy()
+    return res, left, stats
+
+
+def tile_of_pixels(w, h):
+    """tile number (blocks of 8x8 tiles, row-major blocks) of every pixel, row-major"""
+    y, x = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    blk = (y // 64) * (w // 64) + (x // 64)
+    return (blk * 64 + ((y % 64) // 8) * 8 + (x % 64) // 8).reshape(-1)
+
+
+def check(res, left, g_hits, g_mask, rays, w, h):
+    tiles = tile_of_pixels(w, h)
+    handed = np.isin(tiles, left)
+    untouched = res.view(np.uint32).reshape(-1, 4)[:, 0] == 0x7e7e7e7e
+    assert (untouched == handed).all(), "a tile is either answered or handed back"
+    done = ~handed
+    hit = res["prim"] != NONE
+    assert (hit[done] == g_mask[done]).all()
+    sel = done & hit
+    assert (res["prim"][sel] == g_hits["triangle_index"][sel]).all()
+    for fld in ("t", "u", "v"):
+        assert (res[fld][sel].view(np.uint32) == g_hits[fld][sel].view(np.uint32)).all(), fld
+    return done
+
+
+def test_packet_kernel_from_the_root_and_from_shared_entry_points(packet_obj, oracle, scene):
+    tv, tr, nodes = scene
+    rays = camera(0.02, 0.05, 0.55)                         # every direction component positive: no tile is handed back
+    g_hits, g_mask = chain_oracle(oracle, tv, rays)
+    assert 0.2 < g_mask.mean() < 0.98
+    root, left, st_root = run_packet_kernel(packet_obj, nodes, tr, rays, W, H)
+    assert len(left) == 0 and check(root, left, g_hits, g_mask, rays, W, H).all()
+    ent = beam_entries(nodes, rays, W, H, bound=2.0, target=12)
+    assert (ent["count"] > 1).all()
+    shared, left, st_ent = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, entries=ent)
+    assert len(left) == 0 and shared.tobytes() == root.tobytes()
+    # a zoomed-in camera (a block's beam is small against the nodes, as at 4096 x 4096 on the 1M-triangle scene): here the shared
+    # walk through the top of the tree pays -- fewer instructions for the same records
+    zoom = camera(0.20, 0.22, 0.05)
+    z_hits, z_mask = chain_oracle(oracle, tv, zoom)
+    z_root, left, st_root = run_packet_kernel(packet_obj, nodes, tr, zoom, W, H, workgroups=1)
+    assert len(left) == 0 and check(z_root, left, z_hits, z_mask, zoom, W, H).all()
+    z_ent = beam_entries(nodes, zoom, W, H, bound=2.0, target=6)
+    z_shared, left, st_ent = run_packet_kernel(packet_obj, nodes, tr, zoom, W, H, entries=z_ent, workgroups=1)
+    assert len(left) == 0 and z_shared.tobytes() == z_root.tobytes()
+    print("instructions per tile: from the root %.0f, from shared entry points %.0f (lists of %s entries)" % (
+        sum(s["total"] for s in st_root) / 128.0, sum(s["total"] for s in st_ent) / 128.0, z_ent["count"].tolist()))
+
+
+def test_tiles_outside_the_beam_start_at_the_root(packet_obj, oracle, scene):
+    """A list made for OTHER rays (a narrower camera): the tiles' own rays fail the beam check and the results are unchanged."""
+    tv, tr, nodes = scene
+    rays = camera(0.02, 0.05, 0.55)
+    root, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, workgroups=1)
+    other = beam_entries(nodes, camera(0.2, 0.2, 0.1), W, H, bound=2.0, target=12)
+    res, left2, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, entries=other, workgroups=1)
+    assert len(left) == 0 and len(left2) == 0 and res.tobytes() == root.tobytes()
+
+
+def test_mixed_sign_tiles_are_handed_back(packet_obj, oracle, scene):
+    """A camera that looks straight at the scene: the tiles across the image's axes have rays of both signs and go to the C++
+    kernel (their block has no list either); everything else is answered, with and without lists."""
+    tv, tr, nodes = scene
+    rays = camera(-0.25, -0.12, 0.5)
+    g_hits, g_mask = chain_oracle(oracle, tv, rays)
+    ent = beam_entries(nodes, rays, W, H, bound=2.0, target=12)
+    res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, entries=ent)
+    done = check(res, left, g_hits, g_mask, rays, W, H)
+    assert 0 < len(left) < W * H // 64 and done.any()
+    assert len(np.unique(left)) == len(left)
