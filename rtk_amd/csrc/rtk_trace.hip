@@ -961,7 +961,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (p.dynamic || packet || counted) RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
 	// entry points shared by the tiles of a 64x64-pixel block (rtk_packet_entries_kernel, one small launch ahead of the traversal)
 	static const int entries_default = getenv("RTK_AMD_PACKET_ENTRIES") ? atoi(getenv("RTK_AMD_PACKET_ENTRIES")) : 1;
-	static const unsigned entries_target = getenv("RTK_AMD_ENTRY_TARGET") ? (unsigned)atoi(getenv("RTK_AMD_ENTRY_TARGET")) : 20u;
+	static const unsigned entries_target = getenv("RTK_AMD_ENTRY_TARGET") ? (unsigned)atoi(getenv("RTK_AMD_ENTRY_TARGET")) : 26u;   // (list size at which the walk stops: 20 / 24 / 28 / 32 / 36 -> 17.7 / 18.0 / 18.0 / 17.9 / 17.85 Grays/s on config 2, profiles/r04_packet_entries.log)
 	if (packet && p.tile_blocks && entries_default != 0 && ds->bound_abs < 0x1p19f && ds->view.num_nodes != 0u &&
 		!(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_ENTRIES))) {
 		const size_t nblk = (size_t)(p.image_w >> 6) * (p.image_h >> 6);

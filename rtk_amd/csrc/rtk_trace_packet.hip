@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 
 
 // ---- entry points shared by the 64 tiles of a 64x64-pixel block (PkBlockEntries, rtk_trace_shared.h) ---------------------
-// One wave per block. The beam: 64 of the block's boundary pixels give a box of origins, a box of reciprocal directions (the same
+// One wave per block. The beam: nine of the block's rays (corners, edge midpoints, centre) give a box of origins, a box of reciprocal directions (the same
 // IEEE quotient the tiles compute) and the smallest min_t; every tile checks its own rays against these before it uses the list
 // (for a pinhole camera the boundary bounds the interior exactly; any other camera just fails the check and starts at the root).
 // The interval slab test: per axis a lower bound of the entry parameter and an upper bound of the exit parameter over the
@@ -683,13 +683,13 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 	uint32_t s_and = 7u, s_or = 0u;
 	float tmin = INFINITY;
 	for (int a = 0; a < 3; a++) { b.olo[a] = INFINITY; b.ohi[a] = -INFINITY; b.rlo[a] = INFINITY; b.rhi[a] = -INFINITY; }
-	{
-		// 64 boundary pixels of the block, one per lane and ONE round of loads: sixteen per side, the corners among them (for a
-		// pinhole camera -- reciprocal directions monotone in the pixel -- the corners alone bound the block; what any other camera
-		// puts outside these bounds fails the tiles' own check and costs speed, never a hit)
-		const uint32_t side = lane >> 4, i = lane & 15u, at = (i * 63u + 7u) / 15u;
-		const uint32_t x = side == 0u ? at : (side == 1u ? at : (side == 2u ? 0u : 63u));
-		const uint32_t y = side == 0u ? 0u : (side == 1u ? 63u : at);
+	if (lane < 9u) {
+		// Nine rays of the block: corners, edge midpoints, centre -- three rows of the image (with one ray per lane along the whole
+		// boundary, 64 rows and as many pages of a 512 MB ray buffer, the loads alone took ~10 us of this kernel's 30). For a pinhole
+		// camera -- reciprocal directions monotone in the pixel -- the corners bound the block exactly; what any other camera puts
+		// outside these bounds fails the tiles' own check against the beam and costs speed, never a hit.
+		const uint32_t x = (lane % 3u) == 0u ? 0u : ((lane % 3u) == 1u ? 31u : 63u);
+		const uint32_t y = (lane / 3u) == 0u ? 0u : ((lane / 3u) == 1u ? 31u : 63u);
 		const rtk_ray r = rays[(size_t)(by * 64u + y) * image_w + bx * 64u + x];
 		const float o[3] = { r.origin.x, r.origin.y, r.origin.z }, d[3] = { r.direction.x, r.direction.y, r.direction.z };
 		uint32_t sg = 0;

@@ -7,4 +7,4 @@ import json,sys,os
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('entries=%s target=%s' % (os.environ.get('RTK_AMD_PACKET_ENTRIES','1'), os.environ.get('RTK_AMD_ENTRY_TARGET','20')), '$*', d['value'], 'Mrays/s', d['roofline']['kernel_ms'], d['roofline']['visits_per_ray'])" || exit 1; }
 RTK_AMD_PACKET_ENTRIES=0 run
-for t in 8 12 20 28 40; do RTK_AMD_ENTRY_TARGET=$t run; done
+for t in 20 24 28 32 36; do RTK_AMD_ENTRY_TARGET=$t run; done

@@ -2,7 +2,7 @@
 # round 4: rocprofv3 evidence for one workload: kernel-trace stats + PMC passes, summarised into gpurun_out/profiles_r04/
 # usage: i_profile.sh <workload> [passes]
 WL=$1
-export RTK_AMD_ENTRY_TARGET=${RTK_AMD_ENTRY_TARGET:-28}
+
 bash scripts/profile_workload.sh $WL prof_r04_$WL
 case $WL in
   coherent) K="rtk_packet_hot";;

@@ -62,8 +62,8 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
         for blk in range(bpr * rows):
             bx, by = blk % bpr, blk // bpr
             sub = img[by * 64:by * 64 + 64, bx * 64:bx * 64 + 64]
-            at = (np.arange(16) * 63 + 7) // 15                      # sixteen pixels per side, the corners among them
-            edge = np.concatenate([sub[0, at], sub[63, at], sub[at, 0], sub[at, 63]])
+            at = np.array([0, 31, 63])                                # corners, edge midpoints, centre
+            edge = sub[np.ix_(at, at)].reshape(-1)
             o, d = edge["origin"], edge["direction"]
             rd = (f(1.0) / d).astype(f)
             e = out[blk]
