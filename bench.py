@@ -616,7 +616,9 @@ def main():
         # SURVEY.md section 8d, build formula with this build's sizes: 36 B positions in, the sort item out (< 2^24 triangles:
         # one 8-B word = 40-bit code over the index, 5 passes; else a 12-B (key, index) pair, 8 passes), P passes x item read +
         # written, 2 x 32 B binary node (refit write, collapse read), 128 B x wide nodes per triangle + 48 B triangle record out
-        passes, item = (5, 8) if cfg["num_tris"] < (1 << 24) else (8, 12)
+        # (key width from n: ceil(log2 n) + 8 bits in whole 8-bit passes, 3 ... 5 of them for the 8-byte words; rtk_build.hip)
+        lg = int(np.ceil(np.log2(max(2, cfg["num_tris"]))))
+        passes, item = (min(5, max(3, (lg + 8 + 7) // 8)), 8) if cfg["num_tris"] < (1 << 24) else (8, 12)
         bpt = 36 + item + passes * 2 * item + 64 + 128.0 * info["num_nodes"] / cfg["num_tris"] + 48
         gbs = cfg["num_tris"] * bpt / (build_ms_device_mesh * 1e-3) / 1e9
         out["build"] = {"triangles": cfg["num_tris"], "ms": round(build_ms_device_mesh, 3), "what": "rtk_dev_scene_build, mesh resident in HBM, "

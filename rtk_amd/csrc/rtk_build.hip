@@ -230,9 +230,9 @@ __global__ void k_morton(const InTri *in_tris, uint32_t n, const uint32_t *bound
 		keys[i] = code >> drop_bits;                               // most significant bits only
 		vals[i] = i;
 	} else {
-		// fewer than 2^24 triangles: the top 40 bits of the code above the triangle's own number. One 8-byte word per
-		// triangle goes through five sort passes instead of a 12-byte pair through six.
-		keys[i] = ((code >> 23) << 24) | (unsigned long long)i;
+		// fewer than 2^24 triangles: the top `63 - drop_bits` (24 ... 40, a multiple of 8) bits of the code above the triangle's
+		// own number. One 8-byte word per triangle goes through three to five sort passes instead of a 12-byte pair through six.
+		keys[i] = ((code >> drop_bits) << 24) | (unsigned long long)i;
 	}
 }
 
@@ -1798,6 +1798,19 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	unsigned long long *keys_a = ar.take<unsigned long long>(n), *keys_b = ar.take<unsigned long long>(n);
 	// index fits under a 40-bit code in one word (RTK_AMD_SORT_PACKED=0: the >= 2^24-triangle path, for tests on small scenes)
 	const bool packed = n < (1u << 24) && !(getenv("RTK_AMD_SORT_PACKED") && atoi(getenv("RTK_AMD_SORT_PACKED")) == 0);
+	// Key width from n: ceil(log2 n) + 8 bits of the code, rounded up to whole 8-bit passes -- every triangle still gets hundreds
+	// of cells of its own on average, the splits below that are decided by the triangle's number (words are all different). The lab
+	// found identical trees down to 30 bits at 1M triangles, and the 10M-triangle build has the same 4 709 302 nodes at 32 bits as at
+	// 40 (profiles/r04_build_ab.log): 32 bits = FOUR passes wherever the index fits the word (n < 2^24), three below 64 k triangles.
+	uint32_t packed_bits = 40u;
+	{
+		uint32_t lg = 0;
+		while ((1ull << lg) < (unsigned long long)n) lg++;
+		packed_bits = ((lg + 8u + 7u) / 8u) * 8u;
+		if (packed_bits < 24u) packed_bits = 24u;
+		if (packed_bits > 40u) packed_bits = 40u;
+		if (getenv("RTK_AMD_KEY_BITS")) { const int kb = atoi(getenv("RTK_AMD_KEY_BITS")); if (kb >= 8 && kb <= 40 && kb % 8 == 0) packed_bits = (uint32_t)kb; }
+	}
 	uint32_t *vals_a = packed ? nullptr : ar.take<uint32_t>(n), *vals_b = packed ? nullptr : ar.take<uint32_t>(n);
 	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
 	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());
@@ -1806,13 +1819,13 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 			const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
 			hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, bs, in_tris, n, d_bounds);
 		}
-		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, n, d_bounds, keys_a, vals_a, 63u - key_bits);
+		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, n, d_bounds, keys_a, vals_a, 63u - (packed ? packed_bits : key_bits));
 		BUILD_CHECK(hipGetLastError());
 	}
 	stage("morton");
 
 	// ---- 4 sort: no allocation, no host synchronisation ------------------------------------
-	const bool in_b = packed ? rtk_sort_words_async(keys_a, keys_b, n, 24u, 64u, sort_scratch, bs)
+	const bool in_b = packed ? rtk_sort_words_async(keys_a, keys_b, n, 24u, 24u + packed_bits, sort_scratch, bs)
 	                         : rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, bs);
 	const unsigned long long *keys = in_b ? keys_b : keys_a;      // packed: all different (the index is part of the word), in ascending order
 	const uint32_t *vals = packed ? nullptr : (in_b ? vals_b : vals_a);

@@ -228,7 +228,13 @@ def _morton_keys(tris):
         v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
         return v
     k = (spread(q[:, 0]) << np.uint64(2)) | (spread(q[:, 1]) << np.uint64(1)) | spread(q[:, 2])
-    return k >> np.uint64(15) if len(t) < (1 << 24) else k
+    if len(t) >= (1 << 24):
+        return k
+    # the packed sort word keeps ceil(log2 n) + 8 bits of the 63-bit code, in whole 8-bit radix passes, 24 ... 40 of them
+    # (rtk_build.hip: key width from n)
+    lg = int(np.ceil(np.log2(max(2, len(t)))))
+    bits = min(40, max(24, ((lg + 8 + 7) // 8) * 8))
+    return k >> np.uint64(63 - bits)
 
 
 @pytest.mark.parametrize("n", [1000, 4096, 4097, 70001, 1_000_000])
