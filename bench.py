@@ -137,15 +137,14 @@ def other_workload(kind, steps, warmup, frame=4096, with_parity=True):
     build_ms = ds.info()["build_ms"]
     d_rays = synth.t_rays_shadow(n) if shadow else synth.t_rays_incoherent(n)
     rays = d_rays
-    opts = api.make_opts(sort_rays=shadow)
+    opts = api.make_opts(sort_rays=True)      # both per-lane workloads: re-ordered by entry cell inside every timed step (3.0 -> 3.5 / 2.5 -> 4.35 Grays/s)
     out_bytes = 1 if shadow else HIT_BYTES
     d_out = torch.empty(n * out_bytes, dtype=torch.uint8, device="cuda")
     trace = (lambda: ds.trace_any_device(d_rays, n, d_out, opts)) if shadow else (lambda: ds.trace_device(d_rays, n, d_out, opts))
     _, ctr = ds.trace_any_counted(rays, opts) if shadow else ds.trace_counted(rays, opts)
     lane_node_bytes = NODE_BYTES if os.environ.get("RTK_AMD_QNODES", "1") == "0" else 64
     alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * lane_node_bytes + ctr["triangles"] * TRI_BYTES
-    if shadow:
-        alg_bytes += n * (32 + 8 + 2 * 24 + 8)          # the re-ordering pre-pass inside the step (see main)
+    alg_bytes += n * (32 + 8 + 3 * 24 + 8)              # the re-ordering pre-pass inside the step (see main): keys, three radix passes, the word read back
     for _ in range(warmup):
         trace()
     torch.cuda.synchronize()
@@ -224,14 +223,14 @@ def other_workload(kind, steps, warmup, frame=4096, with_parity=True):
     _api.lib().rtk_amd_release_workspace()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     return {"workload": ("config5: 10M-tri soup, GPU LBVH build + %d any-hit shadow rays (re-ordered by entry cell inside every step)" % n) if shadow
-            else ("config3: 1M-tri soup, %d incoherent rays" % n),
+            else ("config3: 1M-tri soup, %d incoherent rays (re-ordered by entry cell inside every step)" % n),
             "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "kernel_ms": round(k_ms, 4),
             "hit_fraction": round(hit_frac, 4), "bvh_build_ms_device_resident_mesh": round(build_ms, 3),
             "algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gb_s": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
             "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "triangles": round(ctr["triangles"] / n, 2)},
             "traffic": traffic, "traffic_source": src if traffic else ("none: %s was measured on other kernel code" % src if pj else None),
             "limiter": {k: v for k, v in lim.items()} if lim else None,
-            "ray_reordering_inside_the_step": bool(shadow), "kernel": ("rtk_lane_hot_any" if shadow else "rtk_lane_hot_closest") + " (hand-written gfx950 assembly) + rtk_trace_kernel on the rays it hands back",
+            "ray_reordering_inside_the_step": True, "kernel": ("rtk_lane_hot_any" if shadow else "rtk_lane_hot_closest") + " (hand-written gfx950 assembly) + rtk_trace_kernel on the rays it hands back",
             "parity_vs_oracle_same_bvh": parity, "end_to_end": end_to_end,
             "setup_s": round(time.time() - t0, 1)}
 
@@ -257,8 +256,8 @@ def main():
     ap.add_argument("--static", action="store_true", help="A/B: one fixed ray per lane instead of persistent refill")
     ap.add_argument("--no-tiling", action="store_true")
     ap.add_argument("--no-packet", action="store_true", help="A/B: image-shaped batch on the per-lane kernel")
-    ap.add_argument("--sort-rays", action="store_true", help="reorder the batch by origin cell first (inside the timed step); the default for --workload shadow")
-    ap.add_argument("--no-sort-rays", action="store_true", help="shadow workload: trace the batch in the order given")
+    ap.add_argument("--sort-rays", action="store_true", help="reorder the batch by entry cell first (inside the timed step); the default for --workload incoherent and shadow")
+    ap.add_argument("--no-sort-rays", action="store_true", help="incoherent / shadow workloads: trace the batch in the order given")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--node-exit", type=int, default=0)
@@ -271,9 +270,10 @@ def main():
                          "multi-rank step loop / gather / timing / JSON plumbing in the CPU tests. Prints no perf claim.")
     args = ap.parse_args()
     DRY = args.dry_run_cpu
-    if args.workload == "shadow" and not args.no_sort_rays:
-        # 2^24 shadow rays in random order on a 10M-triangle scene are bound by lines through the fabric; the library's
-        # RTK_TRACE_SORT_RAYS pre-pass (origin-cell Morton order, part of every timed step) is worth +12 % there
+    if args.workload in ("shadow", "incoherent") and not args.no_sort_rays:
+        # 2^24 rays in random order are bound by L2 misses (the 56 G requests/s wall); the library's
+        # RTK_TRACE_SORT_RAYS pre-pass (entry-cell Morton order, part of every timed step) takes that wall away:
+        # shadow 2.5 -> 4.35 Grays/s, incoherent 3.0 -> 3.5 with the assembly kernels
         args.sort_rays = True
 
     import torch
@@ -455,9 +455,9 @@ def main():
             # the re-ordering pre-pass is inside the timed region: keys (32 B ray read, one 8-B word written: cell key over the
             # ray's number), two radix passes over the words (8 B histogram read + 8 B read + 8 B written each), and the
             # 8-B word the traversal reads per ray instead of counting
-            alg_bytes += n * (32 + 8 + 2 * 24 + 8)
+            alg_bytes += n * (32 + 8 + 3 * 24 + 8)
             per_ray_bytes = alg_bytes
-            unit += "; plus the ray re-ordering pre-pass (96 B per ray), timed with the traversal"
+            unit += "; plus the ray re-ordering pre-pass (120 B per ray: keys, three radix passes over 8-byte words, the word read back), timed with the traversal"
     sync()
 
     for k in range(args.warmup):
@@ -594,8 +594,8 @@ def main():
                                      ("none: %s was measured on other kernel code (kernel_code_sha16 differs)" % traffic_src if pj else None),
                      "unit_of_work": unit,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "kernel": kernel_name if not args.sort_rays else kernel_name + " preceded by the re-ordering pre-pass (rtk_ray_bounds_kernel, "
-                               "rtk_ray_keys_kernel, 2 x k_sort_hist/k_scan_*/k_sort_scatter): kernel_ms is their sum per step",
+                     "kernel": kernel_name if not args.sort_rays else kernel_name + " preceded by the re-ordering pre-pass (rtk_ray_entry_keys_kernel, "
+                               "3 x k_sort_hist/k_scan_block/k_sort_scatter): kernel_ms is their sum per step",
                      "kernel_ms": round(k_ms, 4),
                      "limiter": dict(limiter, fabric_tb_s=round(traffic / pj["kernel_trace"]["average_ns"] / 1e3, 2) if traffic else None,
                                      note=("VALU pipes busy `valu_busy` of the traversal kernel's time at `valu_lane_utilisation` "
