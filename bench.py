@@ -227,6 +227,7 @@ def other_workload(kind, steps, warmup, frame=4096, with_parity=True):
             "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "kernel_ms": round(k_ms, 4),
             "hit_fraction": round(hit_frac, 4), "bvh_build_ms_device_resident_mesh": round(build_ms, 3),
             "algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gb_s": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_by_traffic": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "triangles": round(ctr["triangles"] / n, 2)},
             "traffic": traffic, "traffic_source": src if traffic else ("none: %s was measured on other kernel code" % src if pj else None),
             "limiter": {k: v for k, v in lim.items()} if lim else None,
@@ -587,6 +588,9 @@ def main():
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac_by_traffic": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                     "frac_note": ("`frac` prices the ALGORITHMIC bytes (what the unit of work fetches by SURVEY.md 8d) at the kernel's time; above 1 "
+                                   "it says that the caches serve part of them -- `frac_by_traffic` is the measured fabric traffic over the same time") if achieved > HBM_PEAK_GBS else None,
                      "traffic_unit": ("bytes per launch of the traversal kernel crossing the L2 -> fabric boundary, Infinity-Cache (MALL) hits "
                                       "INCLUDED: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes, %s; the scene is %.0f MB (the MALL "
                                       "holds 256 MiB), so this is %s" % (traffic_src, info.get("total_device_bytes", 0) / 1e6,
