@@ -957,13 +957,16 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	p.spill_cap = (uint32_t)spill_cap;
 	p.counter = sc->d_counter;
 
-	// queue heads and visit counters start from zero; a one-block static launch uses neither
-	if (p.dynamic || packet || counted) RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
 	// entry points shared by the tiles of a 64x64-pixel block (rtk_packet_entries_kernel, one small launch ahead of the traversal)
 	static const int entries_default = getenv("RTK_AMD_PACKET_ENTRIES") ? atoi(getenv("RTK_AMD_PACKET_ENTRIES")) : 1;
 	static const unsigned entries_target = getenv("RTK_AMD_ENTRY_TARGET") ? (unsigned)atoi(getenv("RTK_AMD_ENTRY_TARGET")) : 26u;   // (list size at which the walk stops: 20 / 24 / 28 / 32 / 36 -> 17.7 / 18.0 / 18.0 / 17.9 / 17.85 Grays/s on config 2, profiles/r04_packet_entries.log)
-	if (packet && p.tile_blocks && entries_default != 0 && ds->bound_abs < 0x1p19f && ds->view.num_nodes != 0u &&
-		!(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_ENTRIES))) {
+	static const unsigned entries_levels = getenv("RTK_AMD_ENTRY_LEVELS") ? (unsigned)atoi(getenv("RTK_AMD_ENTRY_LEVELS")) : 8u;
+	const bool entries = packet && p.tile_blocks && entries_default != 0 && ds->bound_abs < 0x1p19f && ds->view.num_nodes != 0u &&
+		!(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_ENTRIES));
+	// queue heads and visit counters start from zero; a one-block static launch uses neither. (With entry lists the pre-pass
+	// kernel clears them itself: a 4.6 us fill kernel and its launch gap less per frame.)
+	if ((p.dynamic || packet || counted) && !entries) RTK_HIP_CHECK(hipMemsetAsync(sc->d_counter, 0, RTK_COUNTER_WORDS * sizeof(unsigned long long), stream), RTK_AMD_ERR_HIP);
+	if (entries) {
 		const size_t nblk = (size_t)(p.image_w >> 6) * (p.image_h >> 6);
 		if (sc->entries_capacity < nblk) {
 			if (sc->d_entries) { RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP); (void)hipFree(sc->d_entries); }
@@ -972,7 +975,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			RTK_HIP_CHECK(hipMalloc(&sc->d_entries, nblk * sizeof(PkBlockEntries)), RTK_AMD_ERR_OOM);
 			sc->entries_capacity = nblk;
 		}
-		rtk_packet_entries_launch(p, (PkBlockEntries *)sc->d_entries, ds->bound_abs > 1.0f ? ds->bound_abs : 1.0f, entries_target, stream);
+		rtk_packet_entries_launch(p, (PkBlockEntries *)sc->d_entries, ds->bound_abs > 1.0f ? ds->bound_abs : 1.0f, entries_target, entries_levels, stream);
 		p.entries = (const PkBlockEntries *)sc->d_entries;
 	}
 	if (hot) {

@@ -670,9 +670,11 @@ __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >
 
 #define PK_FRONTIER 128
 __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *nodes, const rtk_ray *rays, uint32_t image_w, uint32_t blocks_per_row,
-	float bound_abs, uint32_t target, PkBlockEntries *out)
+	float bound_abs, uint32_t target, uint32_t max_levels, PkBlockEntries *out, unsigned long long *counter)
 {
 	__shared__ uint32_t s_ref[2][PK_FRONTIER];
+	// (the launch's queue heads and counters start from zero: cleared here, ahead of the traversal kernels, instead of by a fill kernel)
+	if (blockIdx.x == 0) for (uint32_t w = threadIdx.x; w < (uint32_t)RTK_COUNTER_WORDS; w += 64u) counter[w] = 0ull;
 	__shared__ float s_t[2][PK_FRONTIER];
 	__shared__ uint32_t s_out_ref[PK_MAX_ENTRIES];
 	__shared__ float s_out_t[PK_MAX_ENTRIES];
@@ -724,7 +726,9 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 	bool over = false;
 	if (lane == 0) { s_ref[0][0] = 0u; s_t[0][0] = b.tmin; }
 	__syncthreads();
-	for (int level = 0; level < 14 && n_cur != 0u; level++) {
+	// (a block that looks past the scene's edge finds few nodes per level and would walk to the leaves: the deepest walk is the
+	// kernel's duration -- 30 us at 14 levels, 26 at 8 --, so the walk is capped)
+	for (int level = 0; level < (int)max_levels && n_cur != 0u; level++) {
 		if (level > 0 && n_out + n_cur >= target) break;
 		uint32_t n_next = 0u;
 		for (uint32_t base = 0; base < n_cur; base += 64u) {
@@ -787,10 +791,10 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 }
 } // namespace
 
-void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float bound_abs, unsigned target, hipStream_t stream)
+void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float bound_abs, unsigned target, unsigned max_levels, hipStream_t stream)
 {
 	const uint32_t bpr = p.image_w >> 6, rows = p.image_h >> 6;
-	hipLaunchKernelGGL(rtk_packet_entries_kernel, dim3(bpr * rows), dim3(64), 0, stream, p.sc.nodes, p.rays, p.image_w, bpr, bound_abs, target, out);
+	hipLaunchKernelGGL(rtk_packet_entries_kernel, dim3(bpr * rows), dim3(64), 0, stream, p.sc.nodes, p.rays, p.image_w, bpr, bound_abs, target, max_levels, out, p.counter);
 }
 
 // ---- the hand-written kernel: a code object of its own (rtk_packet_hot.S, assembled by the Makefile), carried in this
