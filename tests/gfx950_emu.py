@@ -479,6 +479,11 @@ class Wave:
             self.vset(ops[0], f(ops[1]).astype(np.float64).view(np.uint64))
         elif op == "v_cvt_f32_f64":
             self.vsetf(ops[0], self.src64(ops[1], True).view(np.float64).astype(np.float32))
+        elif op == "v_fma_f64":
+            # (the kernels only use it where a * b is exact in double precision -- products of converted floats --, so a * b + c is
+            # the single-rounded result)
+            a, b, c = (self.src64(ops[i], True).view(np.float64) for i in (1, 2, 3))
+            self.vset(ops[0], np.asarray(a * b + c, dtype=np.float64).view(np.uint64))
         elif op in ("v_mul_f64", "v_add_f64", "v_min_f64", "v_max_f64"):
             a, b = self.src64(ops[1], True).view(np.float64), self.src64(ops[2], True).view(np.float64)
             if op == "v_mul_f64":
