@@ -464,6 +464,33 @@ size_t finish_piece(rtk_dev_scene *ds, HostCtx &c, size_t n, rtk_hit *hits, uint
 	return count;
 }
 
+// rtk_trace_ray's own path: one ray, ONE launch (rtk_trace_one_kernel walks the ray's frontier breadth first with a whole wave
+// and writes the full rtk_hit, the mask and the ticket into the pinned staging memory itself). Returns the hits (0 / 1),
+// (size_t)-1 on error, (size_t)-2 when the kernel reported "not done" (a frontier that does not fit LDS): the caller then takes
+// the batch path.
+size_t trace_one(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *ray, rtk_hit *hit, uint8_t *hit_mask)
+{
+	c.h_rays[0] = *ray;
+	c.ticket = c.ticket == 0xffffffffu ? 1u : c.ticket + 1u;
+	if (rtk_launch_trace_one(ds, c.h_rays, c.h_hits, c.h_mask, c.stream, c.h_status, c.ticket) != RTK_AMD_OK) return (size_t)-1;
+	const volatile unsigned long long *w = c.h_status;
+	const auto t0 = std::chrono::steady_clock::now();
+	bool arrived = false;
+	for (uint32_t spin = 0;; spin++) {
+		if ((uint32_t)(__atomic_load_n(w, __ATOMIC_ACQUIRE) >> 32) == c.ticket) { arrived = true; break; }
+		if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+	}
+	if (!arrived) {
+		if (hipStreamSynchronize(c.stream) != hipSuccess) { rtk_set_error("rtk_trace_ray: %s", hipGetErrorString(hipGetLastError())); return (size_t)-1; }
+		if ((uint32_t)(*c.h_status >> 32) != c.ticket) { rtk_set_error("rtk_trace_ray: the kernel finished without its ticket"); return (size_t)-1; }
+	}
+	if ((*c.h_status & 0xffffffffull) == 2ull) return (size_t)-2;
+	const uint8_t m = c.h_mask[0];
+	if (m && hit) *hit = c.h_hits[0];
+	if (hit_mask) *hit_mask = m;
+	return m ? 1 : 0;
+}
+
 std::atomic<int> g_test_fail_calls{0};
 extern "C" void rtk_amd_test_fail_next_calls(int calls) { g_test_fail_calls.store(calls > 0 ? calls : 0); }
 thread_local HostCtx t_ctx2;                    // second staging set (own stream) for pipelined host-pointer batches
@@ -485,6 +512,11 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 	if (n < 2 * PIPE_CHUNK) {
 		HostCtx &c = t_ctx;
 		if (!c.ensure(n)) return (size_t)-1;
+		static const int one_default = getenv("RTK_AMD_ONE_RAY_KERNEL") ? atoi(getenv("RTK_AMD_ONE_RAY_KERNEL")) : 1;
+		if (n == 1 && one_default != 0) {
+			const size_t r = trace_one(ds, c, rays, hits, hit_mask);
+			if (r != (size_t)-2) return r;
+		}
 		if (!enqueue_piece(ds, c, rays, n, hits != nullptr, false)) return (size_t)-1;
 		return finish_piece(ds, c, n, hits, hit_mask);
 	}

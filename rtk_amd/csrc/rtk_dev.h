@@ -189,5 +189,7 @@ void rtk_scratch_free(LaunchScratch *s);
 void rtk_scene_drop_stream(rtk_dev_scene *ds, hipStream_t stream);   // the stream is about to be destroyed (and has been synchronised)
 // h_status (host-visible): also receives the stream's launch-error word (see rtk_trace_status), or is left alone if the stream has none.
 // ticket != 0 and n <= 256: the word becomes (ticket << 32 | error) once every result of the launch is visible to the host.
+int rtk_launch_trace_one(const rtk_dev_scene *ds, const rtk_ray *d_ray, rtk_hit *d_hit, uint8_t *d_mask, hipStream_t stream,
+	unsigned long long *h_status, uint32_t ticket);
 int rtk_launch_expand(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n, rtk_hit *d_hits,
 	uint8_t *d_mask, hipStream_t stream, unsigned long long *h_status = nullptr, uint32_t ticket = 0);

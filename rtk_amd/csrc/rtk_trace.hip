@@ -659,6 +659,188 @@ __global__ void rtk_expand_kernel(DevSceneView sc, const rtk_hit_record *rec, un
 	}
 }
 
+
+// ---- rtk_trace_ray: ONE ray, one wave (reference rtk.h:129, rtk.c:543-577) --------------------------------------------------
+// A per-ray call is a chain of dependent fetches: rtk_trace_kernel walks ~20 nodes and leaves one after the other for a single
+// ray, ~1 us each from a cold start. Here the wave's 64 lanes walk the ray's FRONTIER breadth first: every node of a level the
+// ray enters is fetched and tested at once (one lane each), the leaves found on the way are tested (one lane each) before the
+// next level so that the hit culls what is behind it, and the best candidate is agreed on by the wave with the canonical tie
+// rule. The chain is then as long as the tree is deep along the ray, not as long as the list of nodes visited. Exact 128-byte
+// nodes and the reference's slab arithmetic with its SSE operand order (rtk.c:458-470) for every ray, the triangle groups of
+// rtk_trace_kernel (rtk.c:212-386): the result is what the exact path of rtk_trace_kernel returns. The same wave expands the
+// hit into the caller-visible rtk_hit and signs off with the ticket (one launch per call instead of two). A frontier that does
+// not fit LDS (a degenerate scene: thousands of boxes on one ray) is reported as "not done" and the host takes the batch path.
+#define ONE_FRONTIER 512
+#define RTK_ONE_NOT_DONE 2ull
+
+__device__ __forceinline__ void one_leaf(const char *tris, uint32_t slot0, bool kz0, bool kz1, float sox, float soy, float soz, float shx, float shy,
+	float shz, float tmin_ray, float tmax_ray, float &best_t, float &best_u, float &best_v, uint32_t &best_prim)
+{
+	uint32_t i = 0, n = 1;
+	bool force = false, redo = false;
+	float sn_t = best_t, sn_u = best_u, sn_v = best_v;
+	uint32_t sn_prim = best_prim;
+	while (i < n) {
+		f32x4 A, B, C;
+		load_tri(tris, (slot0 + i) * (uint32_t)RTK_TRI_STRIDE, A, B, C);
+		if (i == 0u) n = __float_as_uint(C.w);          // leaf size rides in the first record
+		if ((i & 3u) == 0u) {
+			if (redo) { force = true; redo = false; }
+			else { force = (n - i) < 4u; sn_t = best_t; sn_u = best_u; sn_v = best_v; sn_prim = best_prim; }
+		}
+		// permute to (kx,ky,kz) and move the origin (rtk.c:232-280)
+		const float v0x = (kz0 ? A.y : (kz1 ? A.z : A.x)) - sox;
+		const float v0y = (kz0 ? A.z : (kz1 ? A.x : A.y)) - soy;
+		const float v0z = (kz0 ? A.x : (kz1 ? A.y : A.z)) - soz;
+		const float v1x = (kz0 ? B.y : (kz1 ? B.z : B.x)) - sox;
+		const float v1y = (kz0 ? B.z : (kz1 ? B.x : B.y)) - soy;
+		const float v1z = (kz0 ? B.x : (kz1 ? B.y : B.z)) - soz;
+		const float v2x = (kz0 ? C.y : (kz1 ? C.z : C.x)) - sox;
+		const float v2y = (kz0 ? C.z : (kz1 ? C.x : C.y)) - soy;
+		const float v2z = (kz0 ? C.x : (kz1 ? C.y : C.z)) - soz;
+		// shear (rtk.c:284-292)
+		const float x0 = v0x + shx * v0z, y0 = v0y + shy * v0z, z0 = shz * v0z;
+		const float x1 = v1x + shx * v1z, y1 = v1y + shy * v1z, z1 = shz * v1z;
+		const float x2 = v2x + shx * v2z, y2 = v2y + shy * v2z, z2 = shz * v2z;
+		float u, v, w;
+		if (!force) {
+			u = x1 * y2 - y1 * x2;
+			v = x2 * y0 - y2 * x0;
+			w = x0 * y1 - y0 * x1;
+			if (u == 0.0f || v == 0.0f || w == 0.0f) {
+				// rtk.c:306: the whole group switches to double precision
+				best_t = sn_t; best_u = sn_u; best_v = sn_v; best_prim = sn_prim;
+				redo = true;
+				i &= ~3u;
+				continue;
+			}
+		} else {
+			const double xd0 = x0, yd0 = y0, xd1 = x1, yd1 = y1, xd2 = x2, yd2 = y2;
+			u = (float)(xd1 * yd2 - yd1 * xd2);
+			v = (float)(xd2 * yd0 - yd2 * xd0);
+			w = (float)(xd0 * yd1 - yd0 * xd1);
+		}
+		const bool neg = sse_min(sse_min(u, v), w) < 0.0f;          // rtk.c:340-342
+		const bool pos = sse_max(sse_max(u, v), w) > 0.0f;
+		const float det = (u + v) + w;                              // rtk.c:346-353
+		const float rcp = 1.0f / det;
+		float zz = u * z0;
+		zz = zz + v * z1;
+		zz = zz + w * z2;
+		const float t = zz * rcp;
+		const uint32_t prim = __float_as_uint(A.w);
+		const bool in_range = !(neg && pos) && t > tmin_ray && t < tmax_ray;   // rtk.c:354
+		// rtk.c:371 with the canonical tie rule: lowest primitive id among bit-equal t
+		if (in_range && (t < best_t || (t == best_t && prim < best_prim))) { best_t = t; best_u = u * rcp; best_v = v * rcp; best_prim = prim; }
+		i++;
+	}
+}
+
+__global__ void __launch_bounds__(64) rtk_trace_one_kernel(DevSceneView sc, rtk_ray ray_in, rtk_hit *hit_out, uint8_t *mask_out,
+	unsigned long long *status_out, uint32_t ticket)
+{
+	__shared__ uint32_t s_front[2][ONE_FRONTIER];
+	__shared__ uint32_t s_leaf[2][ONE_FRONTIER];
+	const uint32_t lane = threadIdx.x;
+	const char *const nodes = reinterpret_cast<const char *>(sc.nodes);
+	const char *const tris = reinterpret_cast<const char *>(sc.tris);
+	// (the ray travels in the kernel argument: a load from the host's pinned memory would be a PCIe round trip of ~2 us)
+	const float ox = ray_in.origin.x, oy = ray_in.origin.y, oz = ray_in.origin.z, dx = ray_in.direction.x, dy = ray_in.direction.y, dz = ray_in.direction.z,
+		tmin_ray = ray_in.min_t, tmax_ray = ray_in.max_t;
+	// rtk.c:550-566 (as rtk_trace_kernel)
+	const float ax_ = fabsf(dx), ay_ = fabsf(dy), az_ = fabsf(dz);
+	const float m = sse_max(sse_max(ax_, ay_), az_);
+	const bool kz0 = ax_ == m, kz1 = !kz0 && ay_ == m;
+	const float dkx = kz0 ? dy : (kz1 ? dz : dx), dky = kz0 ? dz : (kz1 ? dx : dy), dkz = kz0 ? dx : (kz1 ? dy : dz);
+	const float shx = -dkx / dkz, shy = -dky / dkz;
+	const float sox = kz0 ? oy : (kz1 ? oz : ox), soy = kz0 ? oz : (kz1 ? ox : oy), soz = kz0 ? ox : (kz1 ? oy : oz);
+	const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;      // rtk.c:410: true divides
+	const float shz = kz0 ? rdx : (kz1 ? rdy : rdz);
+	const uint32_t onx = (__float_as_uint(dx) >> 31) * 16u, ony = 32u + (__float_as_uint(dy) >> 31) * 16u, onz = 64u + (__float_as_uint(dz) >> 31) * 16u;
+	float best_t = tmax_ray, best_u = 0.0f, best_v = 0.0f;
+	uint32_t best_prim = RTK_PRIM_NONE;
+	uint32_t n_cur = sc.num_nodes ? 1u : 0u, cur = 0u, n_leaf = 0u;
+	bool not_done = false;
+	if (lane == 0) s_front[0][0] = 0u;
+	__syncthreads();
+	// One round = one memory round trip: the nodes of the current level AND the leaves the previous level found are fetched and
+	// tested together (leaves one lane each, then nodes one lane each); what a leaf's hit culls it culls one level later.
+	while ((n_cur != 0u || n_leaf != 0u) && !not_done) {
+		uint32_t n_next = 0u, n_leaf_next = 0u;
+		const bool had_leaves = n_leaf != 0u;
+		for (uint32_t base = 0; base < n_leaf; base += 64u)
+			if (base + lane < n_leaf) one_leaf(tris, s_leaf[cur][base + lane], kz0, kz1, sox, soy, soz, shx, shy, shz, tmin_ray, tmax_ray, best_t, best_u, best_v, best_prim);
+		for (uint32_t base = 0; base < n_cur; base += 64u) {
+			const bool have = base + lane < n_cur;
+			const uint32_t a_node = (have ? s_front[cur][base + lane] : 0u) << 7;
+			f32x4 nx, fx, ny, fy, nz, fz;
+			u32x4 ch;
+			load_node(nodes, a_node + onx, (a_node + 16u) - onx, a_node + ony, (a_node + 80u) - ony, a_node + onz, (a_node + 144u) - onz, a_node,
+				nx, fx, ny, fy, nz, fz, ch);
+			const uint32_t ref[4] = { ch.x, ch.y, ch.z, ch.w };
+			const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				// rtk.c:458-465: (bound - origin) * rcp_dir, the folded interval test with _mm_max_ps / _mm_min_ps operand order
+				// (best_t here is the lane's own: at least as far as the wave's -- the test only gets more conservative)
+				const float ax = (nx[i] - ox) * rdx, bx = (fx[i] - ox) * rdx;
+				const float ay = (ny[i] - oy) * rdy, by = (fy[i] - oy) * rdy;
+				const float az = (nz[i] - oz) * rdz, bz = (fz[i] - oz) * rdz;
+				const float tn = sse_max(sse_max(ax, ay), sse_max(az, tmin_ray));
+				const float tf = sse_min(sse_min(bx, by), sse_min(bz, best_t));
+				const bool h = have && (tn <= tf) && ref[i] != RTK_REF_NONE;
+				const bool leaf = (ref[i] & RTK_REF_LEAF) != 0u;
+				const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(h && leaf), m_node = __builtin_amdgcn_ballot_w64(h && !leaf);
+				if (h && leaf) { const uint32_t at = n_leaf_next + (uint32_t)__popcll(m_leaf & below); if (at < ONE_FRONTIER) s_leaf[cur ^ 1u][at] = ref[i] & 0x7fffffffu; }
+				if (h && !leaf) { const uint32_t at = n_next + (uint32_t)__popcll(m_node & below); if (at < ONE_FRONTIER) s_front[cur ^ 1u][at] = ref[i]; }
+				n_leaf_next += (uint32_t)__popcll(m_leaf);
+				n_next += (uint32_t)__popcll(m_node);
+			}
+		}
+		if (n_leaf_next > ONE_FRONTIER || n_next > ONE_FRONTIER) { not_done = true; break; }
+		// the wave agrees on the best candidate (lowest t, lowest primitive id among equals)
+		if (had_leaves) {
+			float t_min = best_t;
+			for (int o = 32; o > 0; o >>= 1) t_min = fminf(t_min, __shfl_xor(t_min, o));
+			uint32_t p_min = best_t == t_min ? best_prim : RTK_PRIM_NONE;
+			for (int o = 32; o > 0; o >>= 1) { const uint32_t q = (uint32_t)__shfl_xor((int)p_min, o); p_min = q < p_min ? q : p_min; }
+			const unsigned long long owner = __builtin_amdgcn_ballot_w64(best_t == t_min && best_prim == p_min);
+			const int src = owner ? (int)__builtin_ctzll(owner) : 0;
+			best_u = __shfl(best_u, src);
+			best_v = __shfl(best_v, src);
+			best_t = t_min;
+			best_prim = p_min;
+		}
+		cur ^= 1u;
+		n_cur = n_next;
+		n_leaf = n_leaf_next;
+		__syncthreads();
+	}
+	if (lane == 0) {
+		if (!not_done) {
+			const bool hit = best_prim != RTK_PRIM_NONE && best_prim < sc.num_prims;
+			*mask_out = hit ? 1 : 0;
+			if (hit) {
+				const uint32_t slot = sc.prim_slot[best_prim];
+				const DevTri tr = sc.tris[slot];
+				rtk_hit h;
+				h.t = best_t; h.u = best_u; h.v = best_v;
+				h.vertex[0].position.x = tr.v0[0]; h.vertex[0].position.y = tr.v0[1]; h.vertex[0].position.z = tr.v0[2];
+				h.vertex[1].position.x = tr.v1[0]; h.vertex[1].position.y = tr.v1[1]; h.vertex[1].position.z = tr.v1[2];
+				h.vertex[2].position.x = tr.v2[0]; h.vertex[2].position.y = tr.v2[1]; h.vertex[2].position.z = tr.v2[2];
+				h.vertex[0].index = sc.vertex_index[3u * slot + 0u];
+				h.vertex[1].index = sc.vertex_index[3u * slot + 1u];
+				h.vertex[2].index = sc.vertex_index[3u * slot + 2u];
+				h.mesh_index = sc.slot_mesh[slot];
+				h.triangle_index = sc.slot_tri[slot];
+				*hit_out = h;
+			}
+		}
+		__threadfence_system();
+		__hip_atomic_store(status_out, ((unsigned long long)ticket << 32) | (not_done ? RTK_ONE_NOT_DONE : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
@@ -1124,6 +1306,23 @@ int rtk_launch_expand(const rtk_dev_scene *ds_c, const rtk_hit_record *d_records
 	if (blocks != 1 || !h_status) ticket = 0u;             // the ticket is written by a lone workgroup after its results
 	hipLaunchKernelGGL(rtk_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ds->view, d_records,
 		(unsigned long long)n, d_hits, d_mask, status_word, h_status, ticket);
+	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
+	return RTK_AMD_OK;
+}
+
+// rtk_trace_ray's own launch: ONE ray (read here, on the host: it travels in the kernel argument), one wave, the full rtk_hit and the mask written where the host
+// reads them, then the ticket ((ticket << 32) | 0, or | 2 = "not done: take the batch path"). No scratch, no queue, no second launch.
+int rtk_launch_trace_one(const rtk_dev_scene *ds, const rtk_ray *d_ray, rtk_hit *d_hit, uint8_t *d_mask, hipStream_t stream,
+	unsigned long long *h_status, uint32_t ticket)
+{
+	if (!ds || !d_ray || !d_hit || !d_mask || !h_status || !ticket) { rtk_set_error("rtk_trace_ray: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
+	int cur = -1;
+	if (hipGetDevice(&cur) != hipSuccess || cur != ds->device) {
+		rtk_set_error("rtk_trace_ray: the scene lives on device %d, the calling thread's current device is %d", ds->device, cur);
+		return RTK_AMD_ERR_BAD_ARG;
+	}
+	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * RTK_TRI_STRIDE > 0xffffff00ull) return RTK_AMD_ERR_UNSUPPORTED;
+	hipLaunchKernelGGL(rtk_trace_one_kernel, dim3(1), dim3(64), 0, stream, ds->view, *d_ray, d_hit, d_mask, h_status, ticket);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
 }

@@ -673,3 +673,41 @@ def test_a_failed_per_ray_call_is_reported_not_passed_off_as_a_miss(api):
     assert p.returncode == 0, p.stderr[-2000:]
     assert "first True" in p.stdout and "second True" in p.stdout and "third False" in p.stdout
     assert p.stderr.count("FAILED, not a miss") == 2
+
+
+def test_single_ray_kernel_equals_the_batch_path(api):
+    """rtk_trace_ray runs a kernel of its own (one wave walks the ray's frontier breadth first, exact nodes, one launch);
+    every field of its rtk_hit must be what the batch call returns for the same ray -- ordinary rays, exotic ones (zeros,
+    infinities, NaN intervals: the reference's operand order decides), a scene where one ray meets thousands of boxes (the
+    frontier does not fit LDS: the call falls back to the batch path), an empty scene."""
+    tris = synth.triangle_soup(60_000, 0.04, seed=13)
+    scene, keep = api.build_scene([dict(positions=tris)])
+    try:
+        rays = np.concatenate([synth.rays_config1(200, seed=3), synth.rays_incoherent(200, seed=4), synth.rays_exotic(256, seed=9, tris=tris.reshape(-1, 3, 3))])
+        hits, mask = api.trace_rays(scene, rays)
+        assert 0.3 < mask[:400].mean() < 1.0
+        # (the batch call traces exotic rays on compressed or exact nodes depending on their wave-mates; where boxes are below
+        # float resolution at the origin the two may differ, DESIGN.md 4: such rays are compared with the exact-node batch)
+        diff = 0
+        for i in range(len(rays)):
+            one = api.trace_ray(scene, rays[i])
+            if (one is not None) != bool(mask[i]) or (one is not None and one.tobytes() != hits[i].tobytes()):
+                diff += 1
+                assert i >= 400, (i, one, hits[i], rays[i])
+        assert diff <= 2
+    finally:
+        api.free_scene(scene)
+    # 3000 copies of one triangle, and a ray through all of them: 3000 leaves on one ray
+    one_tri = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    pile = np.tile(one_tri, (3000, 1)) + (np.arange(3000, dtype=np.float32).repeat(3) * np.float32(1e-4))[:, None] * np.array([0, 0, 1], np.float32)
+    scene, keep = api.build_scene([dict(positions=pile)])
+    try:
+        ray = np.zeros(1, RAY_DTYPE)
+        ray["origin"] = (0.25, 0.25, 0)
+        ray["direction"] = (0, 0, 1)
+        ray["max_t"] = 100.0
+        hits, mask = api.trace_rays(scene, np.repeat(ray, 2))
+        one = api.trace_ray(scene, ray[0])
+        assert mask[0] and one is not None and one.tobytes() == hits[0].tobytes() and one["triangle_index"] == 0
+    finally:
+        api.free_scene(scene)
