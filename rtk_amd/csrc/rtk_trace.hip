@@ -1057,10 +1057,13 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	// ... and of those, the hand-written kernel (rtk_packet_hot.S) takes every tile it can and hands the rest to the C++ kernel:
 	// whole 64x64-pixel blocks, at least two per row, a scene whose planes bound the slab margins and whose leaves are small
 	static const int asm_default = getenv("RTK_AMD_PACKET_ASM") ? atoi(getenv("RTK_AMD_PACKET_ASM")) : 1;
+	// RTK_AMD_PACKET_BEAM (default 1): rtk_packet_beam instead of rtk_packet_hot (0: the per-lane slab tests, A/B and tests)
+	static const int beam_default = getenv("RTK_AMD_PACKET_BEAM") ? atoi(getenv("RTK_AMD_PACKET_BEAM")) : 1;
+	const bool beam = beam_default != 0 && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_BEAM)) && rtk_packet_hot_available(ds->device, nullptr, true);
 	int hot_blocks_per_cu = 0;
 	const bool hot = packet && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
 		ds->bound_abs < 0x1p19f && ds->big_leaf_fraction <= 0.02 && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&
-		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu);
+		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu, beam);
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
 	// Plain closest-hit / any-hit batches on compressed nodes go to the hand-written per-lane kernels (rtk_lane_hot.S); the rays
@@ -1179,7 +1182,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		hp.entries = p.entries;
 		size_t hot_blocks = (size_t)ds->num_cus * (size_t)hot_blocks_per_cu;
 		if (hot_blocks > blocks_needed) hot_blocks = blocks_needed;
-		const int rc = rtk_packet_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream);
+		const int rc = rtk_packet_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream, beam);
 		if (rc != RTK_AMD_OK) return rc;
 		// the tiles it handed back (mixed signs or axes, untame rays, a big leaf, a deep stack), by the C++ kernel
 		// (a small grid: the list is empty for most batches, and a launch that only finds that out should cost next to nothing)

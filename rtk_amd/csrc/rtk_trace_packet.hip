@@ -803,7 +803,7 @@ void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float 
 #include <mutex>
 
 namespace {
-struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; int blocks_per_cu = 0; bool tried = false; };
+struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_beam = nullptr; int blocks_per_cu = 0, beam_blocks_per_cu = 0; bool tried = false; };
 std::mutex g_hot_mutex;
 HotModule g_hot[RTK_MAX_DEVICES];
 
@@ -825,28 +825,35 @@ HotModule *hot_module(int device)
 			int nb = 0;
 			if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
 			h.blocks_per_cu = nb > 7 ? 7 : nb;
+			// rtk_packet_beam (the same file assembled with -DRTK_BEAM): 64 VGPRs, 94 SGPRs, no LDS: eight waves per SIMD
+			if (hipModuleGetFunction(&h.fn_beam, h.mod, "rtk_packet_beam") != hipSuccess) { (void)hipGetLastError(); h.fn_beam = nullptr; }
+			else {
+				nb = 0;
+				if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn_beam, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
+				h.beam_blocks_per_cu = nb > 8 ? 8 : nb;
+			}
 		}
 	}
 	return h.fn ? &h : nullptr;
 }
 } // namespace
 
-bool rtk_packet_hot_available(int device, int *blocks_per_cu)
+bool rtk_packet_hot_available(int device, int *blocks_per_cu, bool beam)
 {
 	HotModule *h = hot_module(device);
-	if (!h) return false;
-	if (blocks_per_cu) *blocks_per_cu = h->blocks_per_cu;
+	if (!h || (beam && !h->fn_beam)) return false;
+	if (blocks_per_cu) *blocks_per_cu = beam ? h->beam_blocks_per_cu : h->blocks_per_cu;
 	return true;
 }
 
-int rtk_packet_hot_launch(int device, const PkHotParams &hp_in, unsigned blocks, hipStream_t stream)
+int rtk_packet_hot_launch(int device, const PkHotParams &hp_in, unsigned blocks, hipStream_t stream, bool beam)
 {
 	HotModule *h = hot_module(device);
-	if (!h) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
+	if (!h || (beam && !h->fn_beam)) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
 	PkHotParams hp = hp_in;
 	size_t size = sizeof(hp);
 	void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &hp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
-	RTK_HIP_CHECK(hipModuleLaunchKernel(h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
+	RTK_HIP_CHECK(hipModuleLaunchKernel(beam ? h->fn_beam : h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
 }
 

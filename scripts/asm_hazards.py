@@ -13,6 +13,7 @@ gfx940-family rules that apply to this code (LLVM GCNHazardRecognizer):
   R5  VALU writes an SGPR              -> v_readlane / v_writelane lane select                  4
   R6  global / buffer store of > 8 B   -> VALU overwrites the data registers                    2
   R7  VALU writes a VGPR               -> v_readfirstlane / v_readlane reads it                 1
+  R8  VALU writes a VGPR               -> a DPP instruction reads it                            2
 
 An instruction is one wait state, `s_nop N` is N + 1. Usage: asm_hazards.py <code object or .o> [...]; exit status 1 on a finding.
 """
@@ -57,6 +58,7 @@ class Ins:
         self.is_store = self.is_vmem and ("store" in o)
         self.is_trans = o.startswith(TRANS)
         self.is_nop = o == "s_nop"
+        self.is_dpp = "_dpp" in o
         self.states = (int(self.operands[0], 0) + 1) if self.is_nop else 1
         self.writes = set()
         self.reads = set()
@@ -148,6 +150,8 @@ def lint(name, ins):
                     findings.append((c, p, "R6 store data overwritten by VALU", 2, gap))
             if c.op.startswith(("v_readfirstlane", "v_readlane")) and (p_vw & vr) and gap < 1:
                 findings.append((c, p, "R7 VALU-written VGPR read by readlane", 1, gap))
+            if c.is_dpp and (p_vw & vr) and gap < 2:
+                findings.append((c, p, "R8 VALU-written VGPR read by a DPP instruction", 2, gap))
     for c, p, what, need, gap in findings:
         print("%s: %s: needs %d wait states, has %d\n    producer %#x  %s\n    consumer %#x  %s" % (name, what, need, gap, p.addr, p.text, c.addr, c.text))
     return len(findings)

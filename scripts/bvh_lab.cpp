@@ -356,6 +356,10 @@ static bool block_slab(const std::vector<Ray> &rs, const Box &b, float &tlo) {
 // directions (same signs), and the interval form of the slab test -- per axis a lower bound of the entry parameter and an upper
 // bound of the exit parameter over ALL rays of the beam. A superset of the exact union above.
 static int PK_BEAM = 0;
+static int PK_TILEBEAM = 0;
+static int PK_CACHE_N = 0, PK_CACHE_T = 0, PK_ZORDER = 0;   // software cache of nodes / triangles per workgroup (direct-mapped slots); tiles of a block in Z order
+struct SwCache { std::vector<int> ntag, ttag; uint64_t nh = 0, nm = 0, th = 0, tm = 0; };
+static thread_local SwCache *g_cache = nullptr;   // the node test of a tile is the interval test of the TILE's own beam (wave-uniform), not 64 per-lane slab tests
 struct Beam { float olo[3], ohi[3], rlo[3], rhi[3]; int neg[3]; float tmin, tmax; };
 static Beam make_beam(const std::vector<Ray> &rs) {
 	Beam b; for (int a = 0; a < 3; a++) { b.olo[a] = 1e30f; b.ohi[a] = -1e30f; b.rlo[a] = 1e30f; b.rhi[a] = -1e30f; b.neg[a] = rs[0].d[a] < 0; }
@@ -431,8 +435,13 @@ static void trace_packet(const std::vector<Ray> &rs, PkCnt &c, const std::vector
 		}
 		if (top >= 0) {
 			const W &w = wide[top];
+			if (g_cache && PK_CACHE_N) { int &tg = g_cache->ntag[(size_t)top % PK_CACHE_N]; if (tg == top) g_cache->nh++; else { g_cache->nm++; tg = top; } }
 			float pay[8][256]; bool any[8]; int n_any = 0;
 			for (int i = 0; i < L; i++) if (live[i]) c.lane_nodes++;
+			if (PK_TILEBEAM) {
+				Beam tb = make_beam(rs); tb.tmax = -1e30f; for (int i = 0; i < L; i++) tb.tmax = std::max(tb.tmax, best[i]);
+				for (int k = 0; k < w.n; k++) { float tlo; any[k] = beam_slab(tb, w.b[k], tlo); for (int i = 0; i < L; i++) pay[k][i] = any[k] ? tlo : NAN; n_any += any[k]; }
+			} else
 			for (int k = 0; k < w.n; k++) {
 				any[k] = false;
 				for (int i = 0; i < L; i++) { float tn; if (live[i] && slab(rs[i], &rd[3 * i], w.b[k], best[i], tn)) { pay[k][i] = tn; any[k] = true; } else pay[k][i] = NAN; }
@@ -459,6 +468,7 @@ static void trace_packet(const std::vector<Ray> &rs, PkCnt &c, const std::vector
 			const Leaf &l = leaves[~top];
 			for (uint32_t p : l.prims) {
 				c.tri_steps++;
+				if (g_cache && PK_CACHE_T) { int &tg = g_cache->ttag[(size_t)p % PK_CACHE_T]; if (tg == (int)p) g_cache->th++; else { g_cache->tm++; tg = (int)p; } }
 				for (int i = 0; i < L; i++) if (live[i]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) { best[i] = PK_ANY ? -3e38f : (float)t; hit[i] = 1; } }
 			}
 			pop = true;
@@ -477,6 +487,67 @@ static void trace_packet(const std::vector<Ray> &rs, PkCnt &c, const std::vector
 	if (tout) *tout = best;
 }
 
+// PK_TILEBEAM == 2: the beam traversal with a wave-uniform stack of {ref, tlo}, testing up to TWO nodes per round (the
+// current one and the top of the stack; lanes 0-31 / 32-63 of the plane-per-lane layout): rounds = dependent memory round trips
+struct PairCnt { uint64_t tiles = 0, node_rounds = 0, nodes_tested = 0, tri_steps = 0, leaf_rounds = 0, pushes = 0, pops = 0, culled = 0; };
+static void trace_packet_pair(const std::vector<Ray> &rs, PairCnt &c, const std::vector<PkEntry> *entries, std::vector<float> *tout, int width) {
+	const int L = (int)rs.size();
+	std::vector<float> best(L); for (int i = 0; i < L; i++) best[i] = rs[i].tmax;
+	Beam tb = make_beam(rs);
+	const int oct = (rs[0].d[0] < 0 ? 1 : 0) | (rs[0].d[1] < 0 ? 2 : 0) | (rs[0].d[2] < 0 ? 4 : 0);
+	struct E { int ref; float tlo; };
+	std::vector<E> stack; size_t next_entry = 0;
+	c.tiles++;
+	auto tmax = [&]() { float m = -1e30f; for (int i = 0; i < L; i++) m = std::max(m, best[i]); return m; };
+	if (!entries) stack.push_back({ 0, 0.f });
+	for (;;) {
+		if (stack.empty()) {
+			if (!entries || next_entry >= entries->size()) break;
+			const PkEntry &e = (*entries)[next_entry++];
+			if (e.tlo > tmax()) break;
+			stack.push_back({ e.ref, e.tlo });
+		}
+		// pop up to `width` live entries
+		std::vector<E> cur;
+		const float tm = tmax();
+		const bool mixed = width >= 10;            // -tb 12: two entries of ANY kind per round (a leaf's triangle is fetched beside a node)
+		const int wd = mixed ? width - 10 : width;
+		while (!stack.empty() && (int)cur.size() < wd) {
+			E e = stack.back();
+			if (!mixed && e.ref < 0 && !cur.empty()) break;          // a leaf waits for its own round
+			stack.pop_back(); c.pops++;
+			if (e.tlo > tm) { c.culled++; continue; }
+			cur.push_back(e);
+			if (!mixed && e.ref < 0) break;
+		}
+		if (cur.empty()) continue;
+		if (!mixed && cur[0].ref < 0) {
+			const Leaf &l = leaves[~cur[0].ref];
+			c.leaf_rounds++;
+			for (uint32_t p : l.prims) { c.tri_steps++; for (int i = 0; i < L; i++) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) best[i] = (float)t; } }
+			continue;
+		}
+		c.node_rounds++;
+		tb.tmax = tm;
+		// children of the LAST popped (deeper in the stack = farther) first, so that the first popped node's nearest child ends on top
+		for (int q = (int)cur.size() - 1; q >= 0; q--) {
+			if (cur[q].ref < 0) {
+				const Leaf &l = leaves[~cur[q].ref];
+				for (uint32_t p : l.prims) { c.tri_steps++; for (int i = 0; i < L; i++) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) best[i] = (float)t; } }
+				continue;
+			}
+			c.nodes_tested++;
+			const W &w = wide[cur[q].ref];
+			int idx[8], m = 0; float tl[8];
+			for (int k = 0; k < w.n; k++) { float tlo; if (beam_slab(tb, w.b[k], tlo)) { idx[m] = k; tl[k] = tlo; m++; } }
+			const uint8_t pm = wperm[(size_t)cur[q].ref * 8 + oct]; int pos[4]; for (int z = 0; z < 4; z++) pos[(pm >> (2 * z)) & 3] = z;
+			std::stable_sort(idx, idx + m, [&](int a, int b) { return pos[a] < pos[b]; });
+			for (int z = m - 1; z >= 0; z--) { stack.push_back({ w.ref[idx[z]], tl[idx[z]] }); c.pushes++; }
+		}
+	}
+	if (tout) *tout = best;
+}
+
 static void packet_lab(int W_, int H_, int nblocks) {
 	// depth + per-octant child order of every wide node
 	wdepth.assign(wide.size(), 0);
@@ -490,10 +561,10 @@ static void packet_lab(int W_, int H_, int nblocks) {
 		wperm[i * 8 + o] = pm;
 	}
 	const int tw = PK_LANES == 64 ? 8 : 16, th = PK_LANES == 256 ? 16 : 8;   // 8x8, 16x8, 16x16
-	PkCnt c; double tsum = 0; uint64_t mism = 0;
+	PkCnt c; PairCnt pc; double tsum = 0; uint64_t mism = 0, gnh = 0, gnm = 0, gth = 0, gtm = 0;
 	const int bx_n = W_ / 64, by_n = H_ / 64;
 #pragma omp parallel
-	{ PkCnt lc; double ls = 0; uint64_t lm = 0;
+	{ PkCnt lc; PairCnt lpc; double ls = 0; uint64_t lm = 0, cnh = 0, cnm = 0, cth = 0, ctm = 0;
 #pragma omp for schedule(dynamic, 1)
 		for (int bi = 0; bi < nblocks; bi++) {
 			const uint64_t h = (uint64_t)(bi + 1) * 0x9E3779B97F4A7C15ull;
@@ -504,22 +575,31 @@ static void packet_lab(int W_, int H_, int nblocks) {
 				std::vector<Ray> all; for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++) all.push_back(mkray(bx * 64 + x, by * 64 + y));
 				block_entries(all, ent, lc); lc.blocks++; lc.entry_list += ent.size();
 			}
-			for (int ty = 0; ty < 64 / th; ty++) for (int tx = 0; tx < 64 / tw; tx++) {
+			SwCache cache; cache.ntag.assign(PK_CACHE_N ? PK_CACHE_N : 1, -1); cache.ttag.assign(PK_CACHE_T ? PK_CACHE_T : 1, -1); g_cache = &cache;
+			for (int tz = 0; tz < (64 / th) * (64 / tw); tz++) {
+				int ty = tz / (64 / tw), tx = tz % (64 / tw);
+				if (PK_ZORDER && tw == 8 && th == 8) { tx = (tz & 1) | ((tz >> 1) & 2) | ((tz >> 2) & 4); ty = ((tz >> 1) & 1) | ((tz >> 2) & 2) | ((tz >> 3) & 4); }
 				std::vector<Ray> rs; for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) rs.push_back(mkray(bx * 64 + tx * tw + x, by * 64 + ty * th + y));
-				std::vector<float> t1; trace_packet(rs, lc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1);
+				std::vector<float> t1; g_cache = &cache;
+				if (PK_TILEBEAM >= 2) { trace_packet_pair(rs, lpc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1, PK_TILEBEAM); lc.tiles++; }
+				else trace_packet(rs, lc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1);
 				for (size_t i = 0; i < rs.size(); i++) { Cnt cc; (void)cc; ls += t1[i] < 1e30f ? t1[i] : 0; }
+				g_cache = nullptr;   // (the check run below is not part of the workgroup's work)
 				if (PK_ENTRY_DEPTH > 0 || PK_ORDER) { PkCnt dummy; std::vector<float> t0; const int s0 = PK_ORDER; PK_ORDER = 0; trace_packet(rs, dummy, nullptr, &t0); PK_ORDER = s0; for (size_t i = 0; i < rs.size(); i++) lm += t0[i] != t1[i]; }
 			}
+			cnh += cache.nh; cnm += cache.nm; cth += cache.th; ctm += cache.tm;
 		}
 #pragma omp critical
-		{ c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
+		{ gnh += cnh; gnm += cnm; gth += cth; gtm += ctm; pc.tiles += lpc.tiles; pc.node_rounds += lpc.node_rounds; pc.nodes_tested += lpc.nodes_tested; pc.tri_steps += lpc.tri_steps; pc.leaf_rounds += lpc.leaf_rounds; pc.pushes += lpc.pushes; pc.pops += lpc.pops; pc.culled += lpc.culled; c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
 		  c.lane_nodes += lc.lane_nodes; c.entries += lc.entries; c.entry_culled += lc.entry_culled; c.pre_steps += lc.pre_steps; c.blocks += lc.blocks; c.entry_list += lc.entry_list; tsum += ls; mism += lm; }
 	}
+	if (PK_TILEBEAM >= 2) { const double T2 = (double)pc.tiles; printf("  beam, %d nodes per round: per tile: node rounds %.2f (nodes tested %.2f) leaf rounds %.2f tri steps %.2f pushes %.2f pops %.2f (culled %.2f) | t mismatches %llu\n", PK_TILEBEAM, pc.node_rounds / T2, pc.nodes_tested / T2, pc.leaf_rounds / T2, pc.tri_steps / T2, pc.pushes / T2, pc.pops / T2, pc.culled / T2, (unsigned long long)mism); return; }
 	const double T = (double)c.tiles; const uint64_t st = c.steps[0] + c.steps[1] + c.steps[2] + c.steps[3] + c.steps[4];
 	printf("  packet %d lanes, entry depth %d, order %d: per tile: node steps %.2f (n_any 0/1/2/3/4: %.2f %.2f %.2f %.2f %.2f) tri steps %.2f pushes %.2f pops %.2f (culled %.2f) lane-nodes/ray %.2f",
 		PK_LANES, PK_ENTRY_DEPTH, PK_ORDER, st / T, c.steps[0] / T, c.steps[1] / T, c.steps[2] / T, c.steps[3] / T, c.steps[4] / T, c.tri_steps / T, c.pushes / T, c.pops / T, c.pops_culled / T, (double)c.lane_nodes / (T * PK_LANES));
 	if (PK_ENTRY_DEPTH > 0) printf(" | entries taken %.2f (+%.2f cut) list %.1f per block, pre-pass steps %.1f per block", c.entries / T, c.entry_culled / T, (double)c.entry_list / c.blocks, (double)c.pre_steps / c.blocks);
 	printf(" | t mismatches %llu\n", (unsigned long long)mism);
+	if (PK_CACHE_N || PK_CACHE_T) printf("  software cache per block, tiles in %s order: nodes %d slots hit %.3f | triangles %d slots hit %.3f\n", PK_ZORDER ? "Z" : "row", PK_CACHE_N, (double)gnh / std::max<uint64_t>(1, gnh + gnm), PK_CACHE_T, (double)gth / std::max<uint64_t>(1, gth + gtm));
 }
 
 static std::vector<Ray> load_rays(const char *f);
@@ -881,6 +961,10 @@ int main(int argc, char **argv) {
 		else if (!strcmp(argv[i], "-pf")) pk_files.push_back(argv[++i]);
 		else if (!strcmp(argv[i], "-pa")) PK_ANY = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-pm")) PK_BEAM = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-tb")) PK_TILEBEAM = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-cn_")) PK_CACHE_N = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-ct_")) PK_CACHE_T = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-pz")) PK_ZORDER = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-norays")) skip_rays = true;
 		else if (!strcmp(argv[i], "-wne")) WS_NODE_EXIT = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-wrm")) WS_REFILL_MIN = atoi(argv[++i]);

@@ -9,6 +9,8 @@ PYTHONPATH=. timeout -k 10 200 python scripts/single_ray_latency.py > gpurun_out
 timeout -k 10 120 ./examples/launch_latency_probe > gpurun_out/profiles_$R/${R}_launch_latency_probe.log 2>&1; echo "probe rc=$?"
 gcc -O2 -o examples/host_latency examples/host_latency.c -Iinclude -Lrtk_amd -lrtk_amd -lpthread -Wl,-rpath,$PWD/rtk_amd 2>/dev/null && timeout -k 10 200 ./examples/host_latency > gpurun_out/profiles_$R/${R}_c_host_latency.log 2>&1; echo "c host rc=$?"
 for wl in coherent incoherent shadow; do bash scripts/r4/i_profile.sh $wl > gpurun_out/prof_${R}_$wl.log 2>&1; echo "profile $wl rc=$?"; done
+# (the bench lines below show `traffic` / `limiter` only from a summary taken on the SAME kernel code: use the ones just made)
+cp gpurun_out/profiles_$R/${R}_*_pmc.json profiles/ 2>/dev/null
 for n in 1000000 10000000; do bash scripts/profile_build.sh $n > gpurun_out/${R}_build_profile_$n.log 2>&1; cp gpurun_out/build_kernel_stats_$n.csv gpurun_out/profiles_$R/${R}_build_kernel_stats_$((n / 1000000))M.csv; done
 bash scripts/r4/k_build_traffic.sh 10000000 r4k_10M > gpurun_out/profiles_$R/${R}_build_traffic.log 2>&1; bash scripts/r4/k_build_traffic.sh 1000000 r4k_1M >> gpurun_out/profiles_$R/${R}_build_traffic.log 2>&1
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/profiles_$R/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; echo "bench default rc=$?"

@@ -56,7 +56,14 @@ def disassemble(path):
             mo = re.search(r"\boffset:(-?(?:0x)?[0-9a-fA-F]+)", rest)
             if mo:
                 mods["offset"] = int(mo.group(1), 0)
-            rest = re.split(r"\s+(?=op_sel|neg_lo|neg_hi|offset:|nt\b|sc0\b|sc1\b|glc\b)", rest)[0]
+            md = re.search(r"\b(quad_perm:\[[0-9,]+\]|row_shl:\d+|row_shr:\d+|row_ror:\d+|row_mirror|row_half_mirror|row_bcast:\d+|wave_\w+:\d+)", rest)
+            if md:
+                mods["dpp"] = md.group(1)
+                for k in ("row_mask", "bank_mask"):
+                    mk = re.search(k + r":(0x[0-9a-fA-F]+|\d+)", rest)
+                    mods[k] = int(mk.group(1), 0) if mk else 0xf
+                mods["bound_ctrl"] = "bound_ctrl" in rest
+            rest = re.split(r"\s+(?=op_sel|neg_lo|neg_hi|offset:|nt\b|sc0\b|sc1\b|glc\b|quad_perm|row_|wave_|bank_mask|bound_ctrl)", rest)[0]
             ops = [o.strip() for o in rest.split(",")] if rest.strip() else []
             kernels[cur][0].append((addr, op, ops, mods))
     return kernels
@@ -143,6 +150,10 @@ class Wave:
             return self.exec
         if tok == "m0":
             return self.m0
+        if tok in ("vcc_lo", "exec_lo"):
+            return (self.vcc if tok == "vcc_lo" else self.exec) & 0xffffffff
+        if tok in ("vcc_hi", "exec_hi"):
+            return (self.vcc if tok == "vcc_hi" else self.exec) >> 32
         m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
         if m:
             a, b = int(m.group(1)), int(m.group(2))
@@ -173,6 +184,14 @@ class Wave:
             self.exec = val & M64
         elif tok == "m0":
             self.m0 = val & 0xffffffff
+        elif tok == "exec_lo":
+            self.exec = (self.exec & ~0xffffffff) | (val & 0xffffffff)
+        elif tok == "exec_hi":
+            self.exec = (self.exec & 0xffffffff) | ((val & 0xffffffff) << 32)
+        elif tok == "vcc_lo":
+            self.vcc = (self.vcc & ~0xffffffff) | (val & 0xffffffff)
+        elif tok == "vcc_hi":
+            self.vcc = (self.vcc & 0xffffffff) | ((val & 0xffffffff) << 32)
         else:
             m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
             if m:
@@ -190,7 +209,7 @@ class Wave:
         m = re.fullmatch(r"v(\d+)", tok)
         if m:
             return self.v[int(m.group(1))]
-        if re.fullmatch(r"s(\d+)|vcc_lo|m0", tok):
+        if re.fullmatch(r"s(\d+)|vcc_lo|vcc_hi|exec_lo|exec_hi|m0", tok):
             return np.full(64, self.sget(tok) & 0xffffffff, dtype=np.uint32)
         return np.full(64, self.const(tok) & 0xffffffff, dtype=np.uint32)
 
@@ -274,7 +293,65 @@ class Wave:
             raise EmuError("unknown branch target %r" % tok)
         return addr + 4 + 4 * (imm - 0x10000 if imm & 0x8000 else imm)
 
+    def dpp_source(self, ctrl, bound_ctrl):
+        """-> (source lane of every lane, lanes whose source exists): the DPP controls of GFX9"""
+        lane = np.arange(64)
+        row = lane & ~15
+        ok = np.ones(64, dtype=bool)
+        m = re.fullmatch(r"quad_perm:\[(\d),(\d),(\d),(\d)\]", ctrl)
+        if m:
+            perm = np.array([int(x) for x in m.groups()])
+            src = (lane & ~3) + perm[lane & 3]
+        elif ctrl == "row_mirror":
+            src = row + 15 - (lane & 15)
+        elif ctrl == "row_half_mirror":
+            src = (lane & ~7) + 7 - (lane & 7)
+        elif ctrl.startswith(("row_shl:", "row_shr:", "row_ror:")):
+            n = int(ctrl.split(":")[1])
+            if ctrl.startswith("row_shl:"):
+                i = (lane & 15) + n
+                ok = i < 16
+            elif ctrl.startswith("row_shr:"):
+                i = (lane & 15) - n
+                ok = i >= 0
+            else:
+                i = ((lane & 15) - n) % 16
+            src = row + (i % 16)
+        elif ctrl == "row_bcast:15":
+            src = row - 1
+            ok = lane >= 16
+        elif ctrl == "row_bcast:31":
+            src = np.full(64, 31)
+            ok = lane >= 32
+        else:
+            raise EmuError("DPP control not modelled: %s" % ctrl)
+        src = np.where(ok, src, lane)
+        ok = ok & _lanes_of(self.exec)[src]            # a source lane that is switched off counts as missing
+        return src, ok
+
     def step(self, addr, op, ops, mods):
+        if op.endswith("_dpp"):
+            src, ok = self.dpp_source(mods["dpp"], mods["bound_ctrl"])
+            tok = ops[1]
+            pre = ""
+            while tok[:1] in "-|":
+                pre += tok[0]; tok = tok[1:]
+            tok = tok.rstrip("|")
+            vals = self.src(tok)[src]
+            lane = np.arange(64)
+            enabled = (((mods["row_mask"] >> (lane >> 4)) & 1) == 1) & (((mods["bank_mask"] >> ((lane >> 2) & 3)) & 1) == 1)
+            if mods["bound_ctrl"]:
+                vals = np.where(ok, vals, 0)
+            else:
+                enabled = enabled & ok
+            self.v[255] = vals
+            ops = [ops[0], pre + "v255" + ("|" if "|" in pre else "")] + list(ops[2:])
+            saved = self.exec
+            self.exec = saved & _mask_of(enabled)
+            try:
+                return self.step(addr, op[:-4], ops, {})
+            finally:
+                self.exec = saved
         base = re.sub(r"_e(32|64)$", "", op)
         if base.startswith("s_"):
             return self.salu(addr, base, ops, mods)
@@ -317,7 +394,7 @@ class Wave:
         elif op == "s_not_b64":
             r = ~g(ops[1]) & M64
             st(ops[0], r); self.scc = int(r != 0)
-        elif op in ("s_and_b64", "s_or_b64", "s_andn2_b64", "s_xor_b64", "s_and_b32", "s_or_b32", "s_andn2_b32"):
+        elif op in ("s_and_b64", "s_or_b64", "s_andn2_b64", "s_xor_b64", "s_and_b32", "s_or_b32", "s_andn2_b32", "s_xor_b32"):
             a, b = g(ops[1]), g(ops[2])
             w = M64 if op.endswith("b64") else 0xffffffff
             kind = op[2:op.rindex("_")]
@@ -335,6 +412,11 @@ class Wave:
         elif op == "s_min_u32":
             a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 0xffffffff
             st(ops[0], min(a, b)); self.scc = int(a < b)
+        elif op == "s_max_i32":
+            a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 0xffffffff
+            a = a - (1 << 32) if a >> 31 else a
+            b = b - (1 << 32) if b >> 31 else b
+            st(ops[0], max(a, b) & 0xffffffff); self.scc = int(a > b)
         elif op in ("s_lshl_b32", "s_lshr_b32"):
             a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 31
             r = (a << b) & 0xffffffff if op == "s_lshl_b32" else a >> b

@@ -136,8 +136,48 @@ def test_packet_entry_points_do_not_change_a_record(api):
         assert ds.trace(rays, opts=api.make_opts(no_asm=True, **img), full=False).tobytes() == ref.tobytes()
         assert ds.trace(rays, opts=api.make_opts(no_asm=True, no_entries=True, **img), full=False).tobytes() == ref.tobytes()
         assert ds.trace(rays, opts=api.make_opts(no_packet=True, **img), full=False).tobytes() == ref.tobytes()
+        # rtk_packet_hot (per-lane slab tests) against the default, rtk_packet_beam (the tile's beam against one child plane per lane)
+        assert ds.trace(rays, opts=api.make_opts(no_beam=True, **img), full=False).tobytes() == ref.tobytes()
+        assert ds.trace(rays, opts=api.make_opts(no_beam=True, no_entries=True, **img), full=False).tobytes() == ref.tobytes()
     # (whether the lists pay depends on how a block's beam compares with the nodes at the cut: they do at 4096 x 4096 on the
     # 1M-triangle scene -- bench.py's roofline block counts the steps -- and need not at this size; records never depend on it)
     _, with_lists = ds.trace_counted(frames[0], api.make_opts(image=(w, h)))
     _, from_root = ds.trace_counted(frames[0], api.make_opts(image=(w, h), no_entries=True))
     assert with_lists["wave_node_steps"] != from_root["wave_node_steps"] and with_lists["rays"] == from_root["rays"] == w * h
+
+
+def test_packet_beam_kernel_on_every_octant_and_on_rays_of_their_own(api):
+    """rtk_packet_beam: cameras on all eight sides of the scene (every direction octant has its own plane rows and order word),
+    a frame whose rays all have origins, min_t and max_t of their own (the wave-wide minima / maxima of the tile's beam instead
+    of the pinhole shortcut; short rays end at a max_t inside the scene), and a frame with negative min_t (its tiles are handed
+    to the C++ kernel). Records equal the C++ per-lane kernel's."""
+    tris = synth.triangle_soup(300_000, 0.03, 7)
+    ds = api.DeviceScene.build([dict(positions=tris)])
+    w = h = 512
+    base = synth.rays_pinhole(w, h)
+    frames = []
+    for o in range(8):
+        r = base.copy()
+        sx, sy, sz = (-1.0 if o & 1 else 1.0), (-1.0 if o & 2 else 1.0), (-1.0 if o & 4 else 1.0)
+        # an off-axis camera: every ray of the frame has the octant's signs
+        r["direction"][:, 0] = (np.abs(r["direction"][:, 0]) * np.float32(0.5) + np.float32(0.05)) * np.float32(sx)
+        r["direction"][:, 1] = (np.abs(r["direction"][:, 1]) * np.float32(0.5) + np.float32(0.05)) * np.float32(sy)
+        r["direction"][:, 2] = np.float32(sz)
+        r["origin"] = (0.5 - 0.35 * sx, 0.5 - 0.35 * sy, 0.5 - 2.0 * sz)
+        frames.append(r)
+    own = base.copy()
+    own["origin"] += (synth.u01(41, 0, w * h * 3).reshape(-1, 3) - np.float32(0.5)) * np.float32(2e-3)
+    own["min_t"] = synth.u01(42, 0, w * h) * np.float32(1.6)
+    own["max_t"] = own["min_t"] + synth.u01(43, 0, w * h) * np.float32(1.5)
+    frames.append(own)
+    behind = base.copy()
+    behind["min_t"] = -1.0
+    frames.append(behind)
+    for i, rays in enumerate(frames):
+        img = dict(image=(w, h))
+        ref = ds.trace(rays, opts=api.make_opts(no_packet=True, **img), full=False)
+        if i < 9:
+            assert (ref["prim"] != 0xFFFFFFFF).mean() > 0.2, i
+        got = ds.trace(rays, opts=api.make_opts(**img), full=False)
+        assert got.tobytes() == ref.tobytes(), i
+        assert ds.trace(rays, opts=api.make_opts(no_beam=True, **img), full=False).tobytes() == ref.tobytes(), i

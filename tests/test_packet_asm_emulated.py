@@ -26,10 +26,15 @@ assert ENTRIES.itemsize == 512
 W, H = 128, 64            # two 64x64-pixel blocks = 128 tiles
 
 
-@pytest.fixture(scope="module")
-def packet_obj():
+# the two kernels assembled from rtk_packet_hot.S: per-lane slab tests (20 KB of LDS for the stacks) and, with -DRTK_BEAM, the
+# interval test of the tile's own beam (one child plane per lane; no LDS)
+KERNELS = {"rtk_packet_hot": ("rtk_packet_hot.o", 20480), "rtk_packet_beam": ("rtk_packet_beam.o", 0)}
+
+
+@pytest.fixture(scope="module", params=sorted(KERNELS))
+def packet_obj(request):
     subprocess.check_call(["make", "-s", "-C", CSRC, os.path.join(os.path.abspath(CSRC), "obj", "rtk_packet_hot.hsaco")])
-    return OBJ
+    return request.param
 
 
 @pytest.fixture(scope="module")
@@ -135,7 +140,7 @@ def run_packet_kernel(obj, nodes, tr, rays, w, h, entries=None, bound=None, work
     bpr = w // 64
     karg = struct.pack("<6Q4IfIQ", a_n, a_t, a_r, a_o, a_c, a_l, (w // 64) * (h // 64), w, bpr, (0x100000000 + bpr - 1) // bpr, bound, 0, a_e)
     assert len(karg) == 80
-    stats = emu.run_kernel(obj, "rtk_packet_hot", mem, karg, workgroups, 20480, max_instructions=6_000_000)
+    stats = emu.run_kernel(os.path.join(CSRC, "obj", KERNELS[obj][0]), obj, mem, karg, workgroups, KERNELS[obj][1], max_instructions=6_000_000)
     res = mem.get(a_o).view(HIT_RECORD_DTYPE).copy()
     counter = mem.get(a_c).view(np.uint64)
     left = mem.get(a_l).view(np.uint32)[:int(counter[10])].copy()
