@@ -1180,7 +1180,9 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		hp.bpr_magic = (uint32_t)((0x100000000ull + hp.blocks_per_row - 1u) / hp.blocks_per_row);
 		hp.bound_abs = ds->bound_abs > 1.0f ? ds->bound_abs : 1.0f;
 		hp.entries = p.entries;
-		size_t hot_blocks = (size_t)ds->num_cus * (size_t)hot_blocks_per_cu;
+		// (RTK_AMD_HOT_BLOCKS_PER_CU: fewer resident workgroups, to tell a latency-bound kernel from a throughput-bound one)
+		static const int hot_bpc_env = getenv("RTK_AMD_HOT_BLOCKS_PER_CU") ? atoi(getenv("RTK_AMD_HOT_BLOCKS_PER_CU")) : 0;
+		size_t hot_blocks = (size_t)ds->num_cus * (size_t)(hot_bpc_env > 0 && hot_bpc_env < hot_blocks_per_cu ? hot_bpc_env : hot_blocks_per_cu);
 		if (hot_blocks > blocks_needed) hot_blocks = blocks_needed;
 		const int rc = rtk_packet_hot_launch(ds->device, hp, (unsigned)hot_blocks, stream, beam);
 		if (rc != RTK_AMD_OK) return rc;
