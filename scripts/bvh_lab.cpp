@@ -548,6 +548,53 @@ static void trace_packet_pair(const std::vector<Ray> &rs, PairCnt &c, const std:
 	if (tout) *tout = best;
 }
 
+// PK_TILEBEAM == 20: one wave walks TWO adjacent 8x8 tiles (a 16x8-pixel tile as two ray groups with a beam each: lanes 0-31 / 32-63 of
+// the plane-per-lane layout test the same node for the two groups): an entry carries the set of groups that enter it; a triangle is
+// tested only for the groups whose own beam reaches its leaf. Counts per 128 rays: node steps, triangle tests per group.
+struct GrpCnt { uint64_t tiles = 0, node_steps = 0, tri_group_tests = 0, leaves = 0, pushes = 0, pops = 0, culled = 0; };
+static void trace_packet_groups(const std::vector<Ray> &rs, int tw, GrpCnt &c, const std::vector<PkEntry> *entries, std::vector<float> *tout) {
+	const int L = (int)rs.size();
+	std::vector<float> best(L); for (int i = 0; i < L; i++) best[i] = rs[i].tmax;
+	std::vector<Ray> g[2]; std::vector<int> gi[2];
+	for (int i = 0; i < L; i++) { const int grp = (i % tw) >= 8 ? 1 : 0; g[grp].push_back(rs[i]); gi[grp].push_back(i); }
+	Beam tb[2] = { make_beam(g[0]), make_beam(g[1]) };
+	const int oct = (rs[0].d[0] < 0 ? 1 : 0) | (rs[0].d[1] < 0 ? 2 : 0) | (rs[0].d[2] < 0 ? 4 : 0);
+	struct E { int ref; float tlo; int gm; };
+	std::vector<E> stack; size_t next_entry = 0;
+	c.tiles++;
+	auto tmax = [&](int grp) { float m = -1e30f; for (int i : gi[grp]) m = std::max(m, best[i]); return m; };
+	if (!entries) stack.push_back({ 0, 0.f, 3 });
+	for (;;) {
+		if (stack.empty()) {
+			if (!entries || next_entry >= entries->size()) break;
+			const PkEntry &e = (*entries)[next_entry++];
+			if (e.tlo > std::max(tmax(0), tmax(1))) break;
+			stack.push_back({ e.ref, e.tlo, 3 });
+		}
+		E e = stack.back(); stack.pop_back(); c.pops++;
+		const float tm[2] = { tmax(0), tmax(1) };
+		int gm = e.gm; for (int q = 0; q < 2; q++) if (e.tlo > tm[q]) gm &= ~(1 << q);
+		if (!gm) { c.culled++; continue; }
+		if (e.ref < 0) {
+			const Leaf &l = leaves[~e.ref]; c.leaves++;
+			for (uint32_t p : l.prims) for (int q = 0; q < 2; q++) if (gm & (1 << q)) { c.tri_group_tests++; for (int i : gi[q]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) best[i] = (float)t; } }
+			continue;
+		}
+		c.node_steps++;
+		const W &w = wide[e.ref];
+		int idx[8], m = 0; float tl[8]; int cg[8];
+		for (int k = 0; k < w.n; k++) {
+			int cm = 0; float lo = 1e30f;
+			for (int q = 0; q < 2; q++) if (gm & (1 << q)) { tb[q].tmax = tm[q]; float tlo; if (beam_slab(tb[q], w.b[k], tlo)) { cm |= 1 << q; lo = std::min(lo, tlo); } }
+			if (cm) { idx[m++] = k; tl[k] = lo; cg[k] = cm; }
+		}
+		const uint8_t pm = wperm[(size_t)e.ref * 8 + oct]; int pos[4]; for (int z = 0; z < 4; z++) pos[(pm >> (2 * z)) & 3] = z;
+		std::stable_sort(idx, idx + m, [&](int a, int b) { return pos[a] < pos[b]; });
+		for (int z = m - 1; z >= 0; z--) { stack.push_back({ w.ref[idx[z]], tl[idx[z]], cg[idx[z]] }); c.pushes++; }
+	}
+	if (tout) *tout = best;
+}
+
 static void packet_lab(int W_, int H_, int nblocks) {
 	// depth + per-octant child order of every wide node
 	wdepth.assign(wide.size(), 0);
@@ -561,10 +608,10 @@ static void packet_lab(int W_, int H_, int nblocks) {
 		wperm[i * 8 + o] = pm;
 	}
 	const int tw = PK_LANES == 64 ? 8 : 16, th = PK_LANES == 256 ? 16 : 8;   // 8x8, 16x8, 16x16
-	PkCnt c; PairCnt pc; double tsum = 0; uint64_t mism = 0, gnh = 0, gnm = 0, gth = 0, gtm = 0;
+	PkCnt c; PairCnt pc; GrpCnt gc; double tsum = 0; uint64_t mism = 0, gnh = 0, gnm = 0, gth = 0, gtm = 0;
 	const int bx_n = W_ / 64, by_n = H_ / 64;
 #pragma omp parallel
-	{ PkCnt lc; PairCnt lpc; double ls = 0; uint64_t lm = 0, cnh = 0, cnm = 0, cth = 0, ctm = 0;
+	{ PkCnt lc; PairCnt lpc; GrpCnt lgc; double ls = 0; uint64_t lm = 0, cnh = 0, cnm = 0, cth = 0, ctm = 0;
 #pragma omp for schedule(dynamic, 1)
 		for (int bi = 0; bi < nblocks; bi++) {
 			const uint64_t h = (uint64_t)(bi + 1) * 0x9E3779B97F4A7C15ull;
@@ -581,7 +628,8 @@ static void packet_lab(int W_, int H_, int nblocks) {
 				if (PK_ZORDER && tw == 8 && th == 8) { tx = (tz & 1) | ((tz >> 1) & 2) | ((tz >> 2) & 4); ty = ((tz >> 1) & 1) | ((tz >> 2) & 2) | ((tz >> 3) & 4); }
 				std::vector<Ray> rs; for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) rs.push_back(mkray(bx * 64 + tx * tw + x, by * 64 + ty * th + y));
 				std::vector<float> t1; g_cache = &cache;
-				if (PK_TILEBEAM >= 2) { trace_packet_pair(rs, lpc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1, PK_TILEBEAM); lc.tiles++; }
+				if (PK_TILEBEAM == 20) { trace_packet_groups(rs, tw, lgc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1); lc.tiles++; }
+				else if (PK_TILEBEAM >= 2) { trace_packet_pair(rs, lpc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1, PK_TILEBEAM); lc.tiles++; }
 				else trace_packet(rs, lc, PK_ENTRY_DEPTH > 0 ? &ent : nullptr, &t1);
 				for (size_t i = 0; i < rs.size(); i++) { Cnt cc; (void)cc; ls += t1[i] < 1e30f ? t1[i] : 0; }
 				g_cache = nullptr;   // (the check run below is not part of the workgroup's work)
@@ -590,9 +638,10 @@ static void packet_lab(int W_, int H_, int nblocks) {
 			cnh += cache.nh; cnm += cache.nm; cth += cache.th; ctm += cache.tm;
 		}
 #pragma omp critical
-		{ gnh += cnh; gnm += cnm; gth += cth; gtm += ctm; pc.tiles += lpc.tiles; pc.node_rounds += lpc.node_rounds; pc.nodes_tested += lpc.nodes_tested; pc.tri_steps += lpc.tri_steps; pc.leaf_rounds += lpc.leaf_rounds; pc.pushes += lpc.pushes; pc.pops += lpc.pops; pc.culled += lpc.culled; c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
+		{ gc.tiles += lgc.tiles; gc.node_steps += lgc.node_steps; gc.tri_group_tests += lgc.tri_group_tests; gc.leaves += lgc.leaves; gc.pushes += lgc.pushes; gc.pops += lgc.pops; gc.culled += lgc.culled; gnh += cnh; gnm += cnm; gth += cth; gtm += ctm; pc.tiles += lpc.tiles; pc.node_rounds += lpc.node_rounds; pc.nodes_tested += lpc.nodes_tested; pc.tri_steps += lpc.tri_steps; pc.leaf_rounds += lpc.leaf_rounds; pc.pushes += lpc.pushes; pc.pops += lpc.pops; pc.culled += lpc.culled; c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
 		  c.lane_nodes += lc.lane_nodes; c.entries += lc.entries; c.entry_culled += lc.entry_culled; c.pre_steps += lc.pre_steps; c.blocks += lc.blocks; c.entry_list += lc.entry_list; tsum += ls; mism += lm; }
 	}
+	if (PK_TILEBEAM == 20) { const double T3 = (double)gc.tiles; printf("  two ray groups per wave (%d lanes): per tile: node steps %.2f leaves %.2f triangle tests per group %.2f pushes %.2f pops %.2f (culled %.2f) | t mismatches %llu\n", PK_LANES, gc.node_steps / T3, gc.leaves / T3, gc.tri_group_tests / T3, gc.pushes / T3, gc.pops / T3, gc.culled / T3, (unsigned long long)mism); return; }
 	if (PK_TILEBEAM >= 2) { const double T2 = (double)pc.tiles; printf("  beam, %d nodes per round: per tile: node rounds %.2f (nodes tested %.2f) leaf rounds %.2f tri steps %.2f pushes %.2f pops %.2f (culled %.2f) | t mismatches %llu\n", PK_TILEBEAM, pc.node_rounds / T2, pc.nodes_tested / T2, pc.leaf_rounds / T2, pc.tri_steps / T2, pc.pushes / T2, pc.pops / T2, pc.culled / T2, (unsigned long long)mism); return; }
 	const double T = (double)c.tiles; const uint64_t st = c.steps[0] + c.steps[1] + c.steps[2] + c.steps[3] + c.steps[4];
 	printf("  packet %d lanes, entry depth %d, order %d: per tile: node steps %.2f (n_any 0/1/2/3/4: %.2f %.2f %.2f %.2f %.2f) tri steps %.2f pushes %.2f pops %.2f (culled %.2f) lane-nodes/ray %.2f",

@@ -16,7 +16,7 @@ from rtk_amd import synth
 from rtk_amd.types import HIT_RECORD_DTYPE, RAY_DTYPE
 
 from . import gfx950_emu as emu
-from .test_lane_asm_emulated import CSRC, NONE, build_bvh4, chain_oracle, oracle   # noqa: F401  (oracle: a fixture)
+from .test_lane_asm_emulated import CSRC, NODE, NONE, TRI, build_bvh4, chain_oracle, child_order, oracle   # noqa: F401  (oracle: a fixture)
 
 OBJ = os.path.join(CSRC, "obj", "rtk_packet_hot.o")
 COUNTER_WORDS = 16 + 16 * 8 + 1
@@ -214,3 +214,48 @@ def test_mixed_sign_tiles_are_handed_back(packet_obj, oracle, scene):
     done = check(res, left, g_hits, g_mask, rays, W, H)
     assert 0 < len(left) < W * H // 64 and done.any()
     assert len(np.unique(left)) == len(left)
+
+
+def comb_tree(levels):
+    """A degenerate tree that makes a traversal's stack deep: node k = [node k + 1, leaf, leaf, leaf], all four boxes the same big
+    box (equal order keys keep the slot order: the chain is entered, three leaves pile up per level); triangles across the view."""
+    m = 3 * levels
+    tv = np.zeros((m, 3, 3), np.float32)
+    for i in range(m):
+        z = np.float32(0.02 * i)
+        tv[i] = [[-3, -3, z], [4, -3, z], [0.5, 5, z]]
+    lo, hi = tv.reshape(-1, 3).min(axis=0) - np.float32(0.5), tv.reshape(-1, 3).max(axis=0) + np.float32(0.5)
+    tr = np.zeros(m, dtype=TRI)
+    for i in range(m):
+        tr[i] = (tv[i, 0], i, tv[i, 1], 1, tv[i, 2], 1)
+    nodes = np.zeros(levels, dtype=NODE)
+    for k in range(levels):
+        last = k + 1 >= levels
+        kids = [NONE if last else k + 1, 0x80000000 | (3 * k), 0x80000000 | (3 * k + 1), 0x80000000 | (3 * k + 2)]
+        if last:
+            kids = kids[1:] + [NONE]
+        for a, ax in enumerate(("bx", "by", "bz")):
+            for s in range(4):
+                empty = kids[s] == NONE
+                nodes[k][ax][0][s] = 1.0 if empty else lo[a]
+                nodes[k][ax][1][s] = -1.0 if empty else hi[a]
+        nodes[k]["child"] = kids
+        nodes[k]["order"] = child_order(nodes[k])
+    return tv, tr, nodes
+
+
+def test_a_stack_deeper_than_the_registers_hands_the_tile_back(packet_obj, oracle):
+    """15 levels x 3 pending leaves fit both kernels' stacks... or not: rtk_packet_hot keeps 20 entries per lane in LDS and
+    hands deeper tiles back, rtk_packet_beam 64 in two registers (a round may push seven: it hands back beyond 56). Whatever a
+    kernel answers equals the oracle; what it hands back it has not touched."""
+    for levels, beam_answers in ((6, True), (15, True), (22, False)):
+        tv, tr, nodes = comb_tree(levels)
+        rays = camera(0.02, 0.05, 0.3)
+        g_hits, g_mask = chain_oracle(oracle, tv, rays)
+        assert g_mask.all()
+        res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, workgroups=1, bound=6.0)
+        done = check(res, left, g_hits, g_mask, rays, W, H)
+        if packet_obj == "rtk_packet_beam":
+            assert done.all() == beam_answers and (beam_answers or not done.any())
+        else:
+            assert done.all() == (levels == 6) and (levels == 6 or not done.any())
