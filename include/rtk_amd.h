@@ -87,7 +87,8 @@ typedef struct rtk_trace_opts {
 #define RTK_TRACE_EXACT_NODES 8u  /* per-lane kernels: read the 128 B exact nodes instead of the 64 B compressed ones (A/B only) */
 #define RTK_TRACE_NO_ASM 16u      /* C++ kernels only, not the hand-written ones (rtk_packet_hot.S, rtk_lane_hot.S) (A/B only) */
 #define RTK_TRACE_NO_ENTRIES 32u  /* image-shaped batch: every tile starts at the root, no per-block entry lists (A/B only) */
-#define RTK_TRACE_NO_BEAM 64u     /* image-shaped batch: rtk_packet_hot (per-lane slab tests) instead of rtk_packet_beam (A/B only) */
+#define RTK_TRACE_NO_BEAM 64u     /* image-shaped batch: rtk_packet_hot (per-lane slab tests) instead of the beam kernels (A/B only) */
+#define RTK_TRACE_ONE_TILE_BEAM 128u /* image-shaped batch: rtk_packet_beam (one tile per wave) instead of rtk_packet_beam2 (A/B only) */
 #define RTK_TRACE_SORT_RAYS 4u   /* reorder the batch by (origin cell, direction octant) before tracing; hits
                                     still land in input order. Pays off for large incoherent batches. */
 

@@ -202,7 +202,7 @@ def to_device(a):
 
 
 def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, exact_nodes=False,
-              no_asm=False, no_entries=False, no_beam=False):
+              no_asm=False, no_entries=False, no_beam=False, one_tile_beam=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
@@ -214,6 +214,8 @@ def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit
         o.flags |= 32      # RTK_TRACE_NO_ENTRIES
     if no_beam:
         o.flags |= 64      # RTK_TRACE_NO_BEAM
+    if one_tile_beam:
+        o.flags |= 128     # RTK_TRACE_ONE_TILE_BEAM
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min

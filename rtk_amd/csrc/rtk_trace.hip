@@ -1057,9 +1057,12 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	// ... and of those, the hand-written kernel (rtk_packet_hot.S) takes every tile it can and hands the rest to the C++ kernel:
 	// whole 64x64-pixel blocks, at least two per row, a scene whose planes bound the slab margins and whose leaves are small
 	static const int asm_default = getenv("RTK_AMD_PACKET_ASM") ? atoi(getenv("RTK_AMD_PACKET_ASM")) : 1;
-	// RTK_AMD_PACKET_BEAM (default 1): rtk_packet_beam instead of rtk_packet_hot (0: the per-lane slab tests, A/B and tests)
-	static const int beam_default = getenv("RTK_AMD_PACKET_BEAM") ? atoi(getenv("RTK_AMD_PACKET_BEAM")) : 1;
-	const bool beam = beam_default != 0 && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_BEAM)) && rtk_packet_hot_available(ds->device, nullptr, true);
+	// RTK_AMD_PACKET_BEAM (default 2): 2 = rtk_packet_beam2 (two tiles per wave), 1 = rtk_packet_beam, 0 = rtk_packet_hot (the
+	// per-lane slab tests); A/B and tests
+	static const int beam_default = getenv("RTK_AMD_PACKET_BEAM") ? atoi(getenv("RTK_AMD_PACKET_BEAM")) : 2;
+	int beam = (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_BEAM)) ? 0 : beam_default;
+	if (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_ONE_TILE_BEAM) && beam == 2) beam = 1;
+	while (beam > 0 && !rtk_packet_hot_available(ds->device, nullptr, beam)) beam--;
 	int hot_blocks_per_cu = 0;
 	const bool hot = packet && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
 		ds->bound_abs < 0x1p19f && ds->big_leaf_fraction <= 0.02 && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&

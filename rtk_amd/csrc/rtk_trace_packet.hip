@@ -803,7 +803,7 @@ void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float 
 #include <mutex>
 
 namespace {
-struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_beam = nullptr; int blocks_per_cu = 0, beam_blocks_per_cu = 0; bool tried = false; };
+struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_beam = nullptr, fn_beam2 = nullptr; int blocks_per_cu = 0, beam_blocks_per_cu = 0, beam2_blocks_per_cu = 0; bool tried = false; };
 std::mutex g_hot_mutex;
 HotModule g_hot[RTK_MAX_DEVICES];
 
@@ -832,28 +832,35 @@ HotModule *hot_module(int device)
 				if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn_beam, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
 				h.beam_blocks_per_cu = nb > 8 ? 8 : nb;
 			}
+			// rtk_packet_beam2 (rtk_packet_beam2.S: two adjacent tiles per wave): 76 VGPRs: six waves per SIMD
+			if (hipModuleGetFunction(&h.fn_beam2, h.mod, "rtk_packet_beam2") != hipSuccess) { (void)hipGetLastError(); h.fn_beam2 = nullptr; }
+			else {
+				nb = 0;
+				if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn_beam2, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
+				h.beam2_blocks_per_cu = nb > 6 ? 6 : nb;
+			}
 		}
 	}
 	return h.fn ? &h : nullptr;
 }
 } // namespace
 
-bool rtk_packet_hot_available(int device, int *blocks_per_cu, bool beam)
+bool rtk_packet_hot_available(int device, int *blocks_per_cu, int beam)
 {
 	HotModule *h = hot_module(device);
-	if (!h || (beam && !h->fn_beam)) return false;
-	if (blocks_per_cu) *blocks_per_cu = beam ? h->beam_blocks_per_cu : h->blocks_per_cu;
+	if (!h || (beam == 1 && !h->fn_beam) || (beam == 2 && !h->fn_beam2)) return false;
+	if (blocks_per_cu) *blocks_per_cu = beam == 2 ? h->beam2_blocks_per_cu : beam == 1 ? h->beam_blocks_per_cu : h->blocks_per_cu;
 	return true;
 }
 
-int rtk_packet_hot_launch(int device, const PkHotParams &hp_in, unsigned blocks, hipStream_t stream, bool beam)
+int rtk_packet_hot_launch(int device, const PkHotParams &hp_in, unsigned blocks, hipStream_t stream, int beam)
 {
 	HotModule *h = hot_module(device);
-	if (!h || (beam && !h->fn_beam)) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
+	if (!h || (beam == 1 && !h->fn_beam) || (beam == 2 && !h->fn_beam2)) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
 	PkHotParams hp = hp_in;
 	size_t size = sizeof(hp);
 	void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &hp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
-	RTK_HIP_CHECK(hipModuleLaunchKernel(beam ? h->fn_beam : h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
+	RTK_HIP_CHECK(hipModuleLaunchKernel(beam == 2 ? h->fn_beam2 : beam == 1 ? h->fn_beam : h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
 }
 

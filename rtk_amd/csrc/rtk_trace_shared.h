@@ -155,6 +155,7 @@ void rtk_packet_launch(const TraceParams &p, unsigned blocks, hipStream_t stream
 // the blocks' entry lists (p.image_w / image_h, 64x64-pixel blocks numbered row by row) into `out`, one wave per block
 void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float bound_abs, unsigned target, unsigned max_levels, hipStream_t stream);
 // the hand-written kernel (rtk_packet_hot.S): can this device run it (module loads), and its launch. blocks_per_cu: resident workgroups.
-// beam: rtk_packet_beam, the variant whose node test is the interval test of the tile's own beam (one child plane per lane)
-bool rtk_packet_hot_available(int device, int *blocks_per_cu, bool beam = false);
-int rtk_packet_hot_launch(int device, const PkHotParams &hp, unsigned blocks, hipStream_t stream, bool beam = false);
+// beam = 1: rtk_packet_beam, the variant whose node test is the interval test of the tile's own beam (one child plane per lane);
+// 2: rtk_packet_beam2, two adjacent tiles per wave (the two halves of the wave test a node for the two tiles' beams)
+bool rtk_packet_hot_available(int device, int *blocks_per_cu, int beam = 0);
+int rtk_packet_hot_launch(int device, const PkHotParams &hp, unsigned blocks, hipStream_t stream, int beam = 0);

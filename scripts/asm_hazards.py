@@ -14,6 +14,7 @@ gfx940-family rules that apply to this code (LLVM GCNHazardRecognizer):
   R6  global / buffer store of > 8 B   -> VALU overwrites the data registers                    2
   R7  VALU writes a VGPR               -> v_readfirstlane / v_readlane reads it                 1
   R8  VALU writes a VGPR               -> a DPP instruction reads it                            2
+  R9  VALU writes a VGPR               -> v_permlane16/32_swap reads it (either operand)        2
 
 An instruction is one wait state, `s_nop N` is N + 1. Usage: asm_hazards.py <code object or .o> [...]; exit status 1 on a finding.
 """
@@ -68,6 +69,9 @@ class Ins:
                                                                                    "v_addc_co_u32_e32", "v_subb_co_u32_e32", "v_subbrev_co_u32_e32")
             if o.startswith(("v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32")) or (o.endswith("_e64") and ("_co_" in o)):
                 n_dst = 2
+            self.is_swap = o.startswith(("v_permlane16_swap", "v_permlane32_swap"))
+            if self.is_swap:
+                n_dst = 0          # both operands are read AND written
             if o.startswith("v_cmp") and o.endswith("_e32"):
                 n_dst = 0 if (self.operands and self.operands[0] != "vcc") else 1
             for d in self.operands[:n_dst]:
@@ -76,6 +80,8 @@ class Ins:
                 self.writes |= {("s", "vcc")}
             for s in self.operands[n_dst:]:
                 self.reads |= regs_of(s)
+            if self.is_swap:
+                self.writes |= self.reads
             if o in ("v_cndmask_b32_e32", "v_addc_co_u32_e32", "v_subb_co_u32_e32", "v_subbrev_co_u32_e32") or o.startswith("v_div_fmas"):
                 self.reads |= {("s", "vcc")}
             if o.startswith(("v_fmac", "v_mac")) and self.operands:
@@ -150,6 +156,8 @@ def lint(name, ins):
                     findings.append((c, p, "R6 store data overwritten by VALU", 2, gap))
             if c.op.startswith(("v_readfirstlane", "v_readlane")) and (p_vw & vr) and gap < 1:
                 findings.append((c, p, "R7 VALU-written VGPR read by readlane", 1, gap))
+            if getattr(c, "is_swap", False) and (p_vw & vr) and gap < 2:
+                findings.append((c, p, "R9 VALU-written VGPR read by a permlane swap", 2, gap))
             if c.is_dpp and (p_vw & vr) and gap < 2:
                 findings.append((c, p, "R8 VALU-written VGPR read by a DPP instruction", 2, gap))
     for c, p, what, need, gap in findings:

@@ -412,6 +412,12 @@ class Wave:
         elif op == "s_min_u32":
             a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 0xffffffff
             st(ops[0], min(a, b)); self.scc = int(a < b)
+        elif op == "s_max_u32":
+            a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 0xffffffff
+            st(ops[0], max(a, b)); self.scc = int(a > b)
+        elif op == "s_lshl1_add_u32":
+            r = ((g(ops[1]) & 0xffffffff) << 1) + (g(ops[2]) & 0xffffffff)
+            st(ops[0], r & 0xffffffff); self.scc = int(r > 0xffffffff)
         elif op == "s_max_i32":
             a, b = g(ops[1]) & 0xffffffff, g(ops[2]) & 0xffffffff
             a = a - (1 << 32) if a >> 31 else a
@@ -584,6 +590,14 @@ class Wave:
             below = (np.uint64(1) << limit) - np.uint64(1)
             cnt = np.array([bin(int(m & b)).count("1") for m, b in zip(mask, below)], dtype=np.uint32)
             self.vset(ops[0], cnt + s(ops[2]))
+        elif op == "v_permlane32_swap_b32":
+            # lanes 32-63 of the first operand <-> lanes 0-31 of the second (gfx950)
+            ra, rb = (int(re.fullmatch(r"v(\d+)", o).group(1)) for o in ops[:2])
+            a, b = self.v[ra].copy(), self.v[rb].copy()
+            if self.exec != M64:
+                raise EmuError("v_permlane32_swap_b32 with lanes switched off is not modelled")
+            self.v[ra][32:] = b[:32]
+            self.v[rb][:32] = a[32:]
         elif op == "v_readlane_b32":
             self.sset(ops[0], int(s(ops[1])[self.sget(ops[2]) & 63]))
         elif op == "v_writelane_b32":

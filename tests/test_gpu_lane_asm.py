@@ -139,6 +139,8 @@ def test_packet_entry_points_do_not_change_a_record(api):
         # rtk_packet_hot (per-lane slab tests) against the default, rtk_packet_beam (the tile's beam against one child plane per lane)
         assert ds.trace(rays, opts=api.make_opts(no_beam=True, **img), full=False).tobytes() == ref.tobytes()
         assert ds.trace(rays, opts=api.make_opts(no_beam=True, no_entries=True, **img), full=False).tobytes() == ref.tobytes()
+        assert ds.trace(rays, opts=api.make_opts(one_tile_beam=True, **img), full=False).tobytes() == ref.tobytes()
+        assert ds.trace(rays, opts=api.make_opts(one_tile_beam=True, no_entries=True, **img), full=False).tobytes() == ref.tobytes()
     # (whether the lists pay depends on how a block's beam compares with the nodes at the cut: they do at 4096 x 4096 on the
     # 1M-triangle scene -- bench.py's roofline block counts the steps -- and need not at this size; records never depend on it)
     _, with_lists = ds.trace_counted(frames[0], api.make_opts(image=(w, h)))
@@ -181,3 +183,4 @@ def test_packet_beam_kernel_on_every_octant_and_on_rays_of_their_own(api):
         got = ds.trace(rays, opts=api.make_opts(**img), full=False)
         assert got.tobytes() == ref.tobytes(), i
         assert ds.trace(rays, opts=api.make_opts(no_beam=True, **img), full=False).tobytes() == ref.tobytes(), i
+        assert ds.trace(rays, opts=api.make_opts(one_tile_beam=True, **img), full=False).tobytes() == ref.tobytes(), i

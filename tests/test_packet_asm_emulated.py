@@ -27,8 +27,8 @@ W, H = 128, 64            # two 64x64-pixel blocks = 128 tiles
 
 
 # the two kernels assembled from rtk_packet_hot.S: per-lane slab tests (20 KB of LDS for the stacks) and, with -DRTK_BEAM, the
-# interval test of the tile's own beam (one child plane per lane; no LDS)
-KERNELS = {"rtk_packet_hot": ("rtk_packet_hot.o", 20480), "rtk_packet_beam": ("rtk_packet_beam.o", 0)}
+# interval test of the tile's own beam (one child plane per lane; no LDS); and rtk_packet_beam2.S: two adjacent tiles per wave
+KERNELS = {"rtk_packet_hot": ("rtk_packet_hot.o", 20480), "rtk_packet_beam": ("rtk_packet_beam.o", 0), "rtk_packet_beam2": ("rtk_packet_beam2.o", 0)}
 
 
 @pytest.fixture(scope="module", params=sorted(KERNELS))
@@ -255,7 +255,7 @@ def test_a_stack_deeper_than_the_registers_hands_the_tile_back(packet_obj, oracl
         assert g_mask.all()
         res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, workgroups=1, bound=6.0)
         done = check(res, left, g_hits, g_mask, rays, W, H)
-        if packet_obj == "rtk_packet_beam":
+        if packet_obj in ("rtk_packet_beam", "rtk_packet_beam2"):
             assert done.all() == beam_answers and (beam_answers or not done.any())
         else:
             assert done.all() == (levels == 6) and (levels == 6 or not done.any())
