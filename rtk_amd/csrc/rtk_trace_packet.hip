@@ -832,12 +832,12 @@ HotModule *hot_module(int device)
 				if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn_beam, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
 				h.beam_blocks_per_cu = nb > 8 ? 8 : nb;
 			}
-			// rtk_packet_beam2 (rtk_packet_beam2.S: two adjacent tiles per wave): 76 VGPRs: six waves per SIMD
+			// rtk_packet_beam2 (rtk_packet_beam2.S: two adjacent tiles per wave): 72 VGPRs: seven waves per SIMD
 			if (hipModuleGetFunction(&h.fn_beam2, h.mod, "rtk_packet_beam2") != hipSuccess) { (void)hipGetLastError(); h.fn_beam2 = nullptr; }
 			else {
 				nb = 0;
 				if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h.fn_beam2, TRACE_BLOCK_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
-				h.beam2_blocks_per_cu = nb > 6 ? 6 : nb;
+				h.beam2_blocks_per_cu = nb > 7 ? 7 : nb;
 			}
 		}
 	}
