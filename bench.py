@@ -448,9 +448,10 @@ def main():
     per_ray_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * (NODE_BYTES if packet_kernel else lane_node_bytes) + ctr["triangles"] * TRI_BYTES
     if packet_kernel:
         alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["wave_node_steps"] * NODE_BYTES + ctr["wave_triangle_steps"] * TRI_BYTES
-        unit = ("tile of 64 rays: each node (128 B) and triangle (48 B) is fetched once per tile (node planes one per lane, triangles through the "
-                "scalar cache); visit and step counts are those of the counting C++ kernel (per-lane slab tests) -- the beam kernel's "
-                "interval test visits a superset: +3 % nodes, +9 % triangles (scripts/bvh_lab.cpp -tb 1)")
+        unit = ("tile of 64 rays: each node (128 B) and triangle (48 B) priced once per tile; visit and step counts are those of the counting "
+                "C++ kernel (per-lane slab tests, one tile per wave). The kernel that runs (rtk_packet_beam2) walks two adjacent tiles per wave "
+                "with the interval test of their beams: 33.5 node steps per PAIR of tiles instead of 2 x 26.2, the same triangle tests "
+                "(scripts/bvh_lab.cpp -tb 20) -- it fetches fewer bytes than this model prices")
     else:
         alg_bytes = per_ray_bytes
         unit = "ray: each lane fetches its own nodes (%d B) and triangles (48 B)" % lane_node_bytes
@@ -556,8 +557,8 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     lane_asm = os.environ.get("RTK_AMD_LANE_ASM", "1") != "0" and lane_node_bytes == 64 and not args.static
-    beam = os.environ.get("RTK_AMD_PACKET_BEAM", "1") != "0"
-    kernel_name = (("rtk_packet_beam" if beam else "rtk_packet_hot") + " (hand-written gfx950 assembly) + rtk_trace_packet_kernel<false> on the tiles it hands back" if packet_kernel else
+    beam = os.environ.get("RTK_AMD_PACKET_BEAM", "2")
+    kernel_name = ({"0": "rtk_packet_hot", "1": "rtk_packet_beam"}.get(beam, "rtk_packet_beam2") + " (hand-written gfx950 assembly) + rtk_trace_packet_kernel<false> on the tiles it hands back" if packet_kernel else
                    ("rtk_lane_hot_%s (hand-written gfx950 assembly) + " % ("any" if shadow else "closest") if lane_asm else "") +
                    "rtk_trace_kernel<%d, false, false, %s>%s" % (1 if shadow else 0, "true" if lane_node_bytes == 64 else "false", " on the rays it hands back" if lane_asm else ""))
     out = {

@@ -88,8 +88,8 @@ def kernel_code_sha16(lib_path, name_parts):
 
 # what each bench workload's committed counter summary was measured on
 WORKLOAD_KERNELS = {
-    # the hand-written packet kernel (the beam variant of rtk_packet_hot.S) and the C++ packet kernel behind it (the tiles it hands back)
-    "coherent": [("rtk_packet_beam",), ("rtk_trace_packet_kernelILb0E",)],
+    # the hand-written packet kernel (rtk_packet_beam2.S: two tiles per wave) and the C++ packet kernel behind it (the tiles it hands back)
+    "coherent": [("rtk_packet_beam2",), ("rtk_trace_packet_kernelILb0E",)],
     # the hand-written per-lane kernels and rtk_trace_kernel<MODE 0 / 1, COUNT false, FILT false, QN true> behind them (the rays they hand back)
     "incoherent": [("rtk_lane_hot_closest",), ("rtk_trace_kernelILi0ELb0ELb0ELb1E",)],
     "shadow": [("rtk_lane_hot_any",), ("rtk_trace_kernelILi1ELb0ELb0ELb1E",)],

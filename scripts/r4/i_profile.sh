@@ -5,7 +5,7 @@ WL=$1
 
 bash scripts/profile_workload.sh $WL prof_r04_$WL
 case $WL in
-  coherent) K="rtk_packet_beam";;
+  coherent) K="rtk_packet_beam2";;
   incoherent) K="rtk_lane_hot_closest";;
   shadow) K="rtk_lane_hot_any";;
 esac
