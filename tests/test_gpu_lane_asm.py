@@ -175,10 +175,17 @@ def test_packet_beam_kernel_on_every_octant_and_on_rays_of_their_own(api):
     behind = base.copy()
     behind["min_t"] = -1.0
     frames.append(behind)
+    # rtk_packet_beam2 walks two tiles per wave: frames in which only the left / only the right tile of every pair leaves its block's
+    # beam (origins moved, except in the pixels the pre-pass samples): the pair starts at the root, the other tile is unharmed
+    xs = np.arange(w * h) % w
+    for pick in ((xs % 16 < 8) & (xs % 64 != 0), (xs % 16 >= 8) & (xs % 64 != 31) & (xs % 64 != 63)):
+        half = base.copy()
+        half["origin"][pick] += np.float32(1e-3)
+        frames.append(half)
     for i, rays in enumerate(frames):
         img = dict(image=(w, h))
         ref = ds.trace(rays, opts=api.make_opts(no_packet=True, **img), full=False)
-        if i < 9:
+        if i != 9:
             assert (ref["prim"] != 0xFFFFFFFF).mean() > 0.2, i
         got = ds.trace(rays, opts=api.make_opts(**img), full=False)
         assert got.tobytes() == ref.tobytes(), i

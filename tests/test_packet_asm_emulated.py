@@ -259,3 +259,19 @@ def test_a_stack_deeper_than_the_registers_hands_the_tile_back(packet_obj, oracl
             assert done.all() == beam_answers and (beam_answers or not done.any())
         else:
             assert done.all() == (levels == 6) and (levels == 6 or not done.any())
+
+
+def test_one_tile_of_a_pair_outside_the_beam(packet_obj, oracle, scene):
+    """rtk_packet_beam2 walks two adjacent tiles per wave: when only the left, or only the right, tile of every pair has rays
+    outside its block's beam (origins moved, except in the pixels the lists are made from), the pair starts at the root; the
+    records are the oracle's either way (the one-tile kernels see the same frames)."""
+    tv, tr, nodes = scene
+    xs = np.arange(W * H) % W
+    for pick in ((xs % 16 < 8) & (xs % 64 != 0), (xs % 16 >= 8) & (xs % 64 != 31) & (xs % 64 != 63)):
+        rays = camera(0.02, 0.05, 0.55)
+        rays["origin"][pick] += np.float32(2e-3)
+        g_hits, g_mask = chain_oracle(oracle, tv, rays)
+        ent = beam_entries(nodes, rays, W, H, bound=2.0, target=12)
+        assert (ent["count"] > 1).all()
+        res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, entries=ent, workgroups=1)
+        assert len(left) == 0 and check(res, left, g_hits, g_mask, rays, W, H).all()
