@@ -223,8 +223,8 @@ def comb_tree(levels):
     tv = np.zeros((m, 3, 3), np.float32)
     for i in range(m):
         z = np.float32(0.02 * i)
-        tv[i] = [[-3, -3, z], [4, -3, z], [0.5, 5, z]]
-    lo, hi = tv.reshape(-1, 3).min(axis=0) - np.float32(0.5), tv.reshape(-1, 3).max(axis=0) + np.float32(0.5)
+        tv[i] = [[0.56, 0.62, z], [0.70, 0.62, z], [0.63, 0.76, z]]       # (a corner of the view: most tiles miss the box at once)
+    lo, hi = tv.reshape(-1, 3).min(axis=0) - np.float32(0.01), tv.reshape(-1, 3).max(axis=0) + np.float32(0.01)
     tr = np.zeros(m, dtype=TRI)
     for i in range(m):
         tr[i] = (tv[i, 0], i, tv[i, 1], 1, tv[i, 2], 1)
@@ -252,13 +252,12 @@ def test_a_stack_deeper_than_the_registers_hands_the_tile_back(packet_obj, oracl
         tv, tr, nodes = comb_tree(levels)
         rays = camera(0.02, 0.05, 0.3)
         g_hits, g_mask = chain_oracle(oracle, tv, rays)
-        assert g_mask.all()
+        assert 0.01 < g_mask.mean() < 0.3
         res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, workgroups=1, bound=6.0)
         done = check(res, left, g_hits, g_mask, rays, W, H)
-        if packet_obj in ("rtk_packet_beam", "rtk_packet_beam2"):
-            assert done.all() == beam_answers and (beam_answers or not done.any())
-        else:
-            assert done.all() == (levels == 6) and (levels == 6 or not done.any())
+        answers = beam_answers if packet_obj in ("rtk_packet_beam", "rtk_packet_beam2") else levels == 6
+        # (the tiles that reach the box: all answered, or all handed back)
+        assert done.all() if answers else (len(left) > 0 and not g_mask[done].any())
 
 
 def test_one_tile_of_a_pair_outside_the_beam(packet_obj, oracle, scene):
