@@ -2,7 +2,9 @@
 """Headline benchmark: Mrays/s, primary closest-hit rays on the 1M-triangle scene.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or bare:
+     without WORLD_SIZE in the environment bench.py starts those N ranks itself as a child process and relays rank 0's line;
+     --gpus N that disagrees with WORLD_SIZE is an error, not a 1-GPU line)
 
 A "step" is one pass of the hot path over one batch: every rank traces its own 4096x4096
 frame (2^24 rays; N=1 is BASELINE.json configs[1], N>1 is configs[3]: frame r on rank r,
@@ -236,6 +238,25 @@ def other_workload(kind, steps, warmup, frame=4096, with_parity=True):
             "setup_s": round(time.time() - t0, 1)}
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher around it: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process on 127.0.0.1 and a free port, pass its stdout (rank 0's one JSON line) and stderr through,
+    return its exit code. The parent imports neither torch nor the library: a process that has initialised the GPU must not
+    start (let alone exec) the ranks."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's peer buffers (task statement, Environment)
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,6 +298,12 @@ def main():
         # shadow 2.5 -> 4.35 Grays/s, incoherent 3.0 -> 3.5 with the assembly kernels
         args.sort_rays = True
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher and NEVER touches a GPU (no torch import, no HIP
+        # call before or after): it starts the N ranks as a CHILD `python -m torch.distributed.run`, relays rank 0's JSON line and
+        # the child's exit code
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -287,13 +314,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+        # a line that says n_gpus = WORLD_SIZE under a command that asked for --gpus N would be read as the N-GPU figure
+        log("error: --gpus %d but WORLD_SIZE %d: refusing to print a line for another world size" % (args.gpus, world))
+        sys.exit(2)
+    if not DRY and world > 1 and torch.cuda.device_count() < world:
+        log("error: --gpus %d but this node shows %d GPUs" % (world, torch.cuda.device_count()))
+        sys.exit(2)
     dev = "cpu" if DRY else "cuda"
 
     def sync():
         if not DRY:
             torch.cuda.synchronize()
 
+    if world > 1:
+        args.no_cpu_baseline = True      # the CPU leg is rank 0's at N = 1 only (torch.distributed.run also pins OMP_NUM_THREADS=1)
     if DRY:
         args.no_cpu_baseline = True
         if world > 1:

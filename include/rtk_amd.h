@@ -152,6 +152,13 @@ int rtk_dev_scene_validate(const rtk_dev_scene *ds, rtk_dev_scene_check *out);
  * Never selected implicitly. Environment RTK_AMD_BUILDER=cpu is read once if this was never called. */
 enum { RTK_AMD_BUILDER_DEVICE = 0, RTK_AMD_BUILDER_CPU_TASKS = 1 };
 int rtk_amd_set_builder(int builder);
+/* Where the two PER-RAY symbols of rtk.h (rtk_trace_ray, rtk_trace_ray_filter; reference rtk.h:129-130) run. HOST (default): on
+ * the calling thread, from the caller's blob -- a synchronous call for one ray cannot drive a GPU (a launch and its completion
+ * are ~7 us before any work; the reference's call is under 1 us), SURVEY.md 8b serves this one symbol on the CPU. GPU: a batch
+ * of one through the one-ray kernel (~25 us). Both return the same bytes. Batch entry points are not affected by this and have
+ * no host form. Environment RTK_AMD_PER_RAY=gpu is read once if this was never called. */
+enum { RTK_AMD_PER_RAY_HOST = 0, RTK_AMD_PER_RAY_GPU = 1 };
+int rtk_amd_set_per_ray(int where);
 int rtk_amd_get_builder(void);
 
 /* Device builds draw their temporaries from one workspace per device that is kept between builds
@@ -256,9 +263,6 @@ size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk
 size_t rtk_trace_rays_filter(const rtk_scene *scene, const rtk_ray *rays, size_t n, rtk_hit *hits, uint8_t *hit_mask,
 	rtk_filter_fn *filter, void *filter_user);
 void rtk_amd_forget_scene(const rtk_scene *scene);
-/* Test hook: the next `calls` host-pointer trace calls of the process (rtk_trace_rays and everything built on it, rtk_trace_ray
- * included) fail the way a transient device error would. */
-void rtk_amd_test_fail_next_calls(int calls);
 
 #ifdef __cplusplus
 }

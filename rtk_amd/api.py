@@ -82,7 +82,7 @@ RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_
                      "rtk_dev_trace_rays_filtered", "rtk_dev_trace_rays_any_filtered", "rtk_dev_trace_status",
                      "rtk_trace_rays_filter", "rtk_amd_shard_range", "rtk_mgpu_create", "rtk_mgpu_destroy", "rtk_mgpu_num_devices",
                      "rtk_mgpu_scene", "rtk_mgpu_build", "rtk_mgpu_upload", "rtk_mgpu_trace_rays", "rtk_mgpu_trace_rays_device",
-                     "rtk_amd_set_builder", "rtk_amd_get_builder", "rtk_amd_test_fail_next_calls",
+                     "rtk_amd_set_builder", "rtk_amd_get_builder", "rtk_amd_set_per_ray",
                      "rtk_mgpu_trace_rays_device_striped", "rtk_mgpu_striped_segment"]
 
 _lib = None

@@ -472,7 +472,9 @@ size_t trace_one(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *ray, rtk_hit *hit
 {
 	c.h_rays[0] = *ray;
 	c.ticket = c.ticket == 0xffffffffu ? 1u : c.ticket + 1u;
-	if (rtk_launch_trace_one(ds, c.h_rays, c.h_hits, c.h_mask, c.stream, c.h_status, c.ticket) != RTK_AMD_OK) return (size_t)-1;
+	const int launched = rtk_launch_trace_one(ds, c.h_rays, c.h_hits, c.h_mask, c.stream, c.h_status, c.ticket);
+	if (launched == RTK_AMD_ERR_UNSUPPORTED) return (size_t)-2;          // (a scene beyond the one-ray kernel's 32-bit offsets: the batch path diagnoses it)
+	if (launched != RTK_AMD_OK) return (size_t)-1;
 	const volatile unsigned long long *w = c.h_status;
 	const auto t0 = std::chrono::steady_clock::now();
 	bool arrived = false;
@@ -492,7 +494,13 @@ size_t trace_one(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *ray, rtk_hit *hit
 }
 
 std::atomic<int> g_test_fail_calls{0};
-extern "C" void rtk_amd_test_fail_next_calls(int calls) { g_test_fail_calls.store(calls > 0 ? calls : 0); }
+// Fault injection for the tests of the per-ray calls' failure reporting. Not in the installed header; a no-op unless the process
+// was started with RTK_AMD_TEST_HOOKS=1 (read once): no code of a production host can make its traces fail through it.
+extern "C" void rtk_amd_test_fail_next_calls(int calls)
+{
+	static const bool armed = getenv("RTK_AMD_TEST_HOOKS") && !strcmp(getenv("RTK_AMD_TEST_HOOKS"), "1");
+	if (armed) g_test_fail_calls.store(calls > 0 ? calls : 0);
+}
 thread_local HostCtx t_ctx2;                    // second staging set (own stream) for pipelined host-pointer batches
 const size_t PIPE_CHUNK = (size_t)1 << 15;      // rays per piece when a batch is pipelined
 
@@ -652,15 +660,56 @@ static bool per_ray_failure(const char *who)
 	return false;
 }
 
-// reference rtk.h:129 / rtk.c:543-577 -- a batch of one on the GPU: one small copy up, two launches, one
-// copy down on the calling thread's own stream, no allocation in steady state. Safe from any number of
-// threads on one scene. A GPU round trip per ray stays orders of magnitude slower than the batch calls;
-// throughput callers use rtk_trace_rays / rtk_dev_trace_rays.
+// The per-ray symbols on the calling thread (rtk_host_trace.cpp): see there why. RTK_AMD_PER_RAY=gpu sends them through the
+// GPU again (a batch of one: rtk_trace_one_kernel, one launch + a ticket, ~25 us).
+int rtk_host_trace_ray(const rtk_scene *scene, const rtk_ray *ray, rtk_hit *hit, const rtk_hit *after);
+int rtk_host_trace_ray_filter(const rtk_scene *scene, const rtk_ray *ray, rtk_hit *hit, rtk_filter_fn *filter, void *user);
+
+static std::atomic<int> g_per_ray_where{-1};           // -1: not decided yet (RTK_AMD_PER_RAY=gpu is read once)
+
+extern "C" int rtk_amd_set_per_ray(int where)
+{
+	if (where != RTK_AMD_PER_RAY_HOST && where != RTK_AMD_PER_RAY_GPU) { rtk_set_error("rtk_amd_set_per_ray: unknown value %d", where); return RTK_AMD_ERR_BAD_ARG; }
+	g_per_ray_where.store(where);
+	return RTK_AMD_OK;
+}
+
+static bool per_ray_on_gpu()
+{
+	int w = g_per_ray_where.load(std::memory_order_relaxed);
+	if (w < 0) {
+		const char *e = getenv("RTK_AMD_PER_RAY");
+		w = (e && !strcmp(e, "gpu")) ? RTK_AMD_PER_RAY_GPU : RTK_AMD_PER_RAY_HOST;
+		g_per_ray_where.store(w);
+	}
+	return w == RTK_AMD_PER_RAY_GPU;
+}
+
+static bool injected_failure(const char *who)
+{
+	if (g_test_fail_calls.load(std::memory_order_relaxed) > 0 && g_test_fail_calls.fetch_sub(1) > 0) {
+		rtk_set_error("%s: injected failure (rtk_amd_test_fail_next_calls)", who);
+		t_fatal = false;
+		return true;
+	}
+	return false;
+}
+
+// reference rtk.h:129 / rtk.c:543-577. Re-entrant, any thread, `*hit` untouched on a miss. Served on the calling thread from
+// the caller's blob (< 1.5 us; profiles/r05_c_host_latency.log); throughput callers use rtk_trace_rays / rtk_dev_trace_rays,
+// which run on the GPU and nowhere else.
 extern "C" bool rtk_trace_ray(const rtk_scene *scene, const rtk_ray *ray, rtk_hit *hit)
 {
+	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray: NULL argument"); return false; }
+	if (!per_ray_on_gpu()) {
+		if (injected_failure("rtk_trace_ray")) return per_ray_failure("rtk_trace_ray");
+		const int r = rtk_host_trace_ray(scene, ray, hit, nullptr);
+		if (r < 0) { t_fatal = true; return per_ray_failure("rtk_trace_ray"); }       // a blob that is not a tree stays one
+		t_per_ray_failures = 0;
+		return r == 1;
+	}
 	uint8_t m = 0;
 	rtk_hit h;
-	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray: NULL argument"); return false; }
 	const size_t r = rtk_trace_rays(scene, ray, 1, &h, &m);
 	if (r == (size_t)-1) return per_ray_failure("rtk_trace_ray");
 	t_per_ray_failures = 0;
@@ -674,6 +723,13 @@ extern "C" bool rtk_trace_ray_filter(const rtk_scene *scene, const rtk_ray *ray,
 {
 	if (!scene || !ray || !hit) { rtk_set_error("rtk_trace_ray_filter: NULL argument"); return false; }
 	if (!filter) return rtk_trace_ray(scene, ray, hit);
+	if (!per_ray_on_gpu()) {
+		if (injected_failure("rtk_trace_ray_filter")) return per_ray_failure("rtk_trace_ray_filter");
+		const int r = rtk_host_trace_ray_filter(scene, ray, hit, filter, filter_user);
+		if (r < 0) { t_fatal = true; return per_ray_failure("rtk_trace_ray_filter"); }
+		t_per_ray_failures = 0;
+		return r == 1;
+	}
 	uint8_t m = 0;
 	rtk_hit h;
 	const size_t r = rtk_trace_rays_filter(scene, ray, 1, &h, &m, filter, filter_user);

@@ -1329,7 +1329,10 @@ int rtk_launch_trace_one(const rtk_dev_scene *ds, const rtk_ray *d_ray, rtk_hit 
 		rtk_set_error("rtk_trace_ray: the scene lives on device %d, the calling thread's current device is %d", ds->device, cur);
 		return RTK_AMD_ERR_BAD_ARG;
 	}
-	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * RTK_TRI_STRIDE > 0xffffff00ull) return RTK_AMD_ERR_UNSUPPORTED;
+	if ((uint64_t)ds->view.num_nodes * 128u > 0xffffff00ull || (uint64_t)ds->view.num_tris * RTK_TRI_STRIDE > 0xffffff00ull) {
+		rtk_set_error("rtk_trace_ray: the one-ray kernel addresses nodes and triangles with 32-bit byte offsets (scene: %u nodes, %u triangles)", ds->view.num_nodes, ds->view.num_tris);
+		return RTK_AMD_ERR_UNSUPPORTED;
+	}
 	hipLaunchKernelGGL(rtk_trace_one_kernel, dim3(1), dim3(64), 0, stream, ds->view, *d_ray, d_hit, d_mask, h_status, ticket);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;

@@ -59,22 +59,18 @@ def stripe_bounds(n_records, world):
     return [shard_range(n_records, j, world) for j in range(world)]
 
 
-_equal_counts_seen = set()
-
-
 def _agreed_counts(n_rec, world, group, device):
-    """counts=None: every rank claims all shards are as long as its own. Verified once per (group, size): the ranks
-    all_gather their record counts (a few bytes; afterwards the steady-state step loop exchanges nothing)."""
-    key = (id(group), world, n_rec)
-    if key not in _equal_counts_seen:
-        mine = torch.tensor([n_rec], dtype=torch.int64, device=device)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine, group=group)
-        got = [int(t.item()) for t in every]
-        if any(g != n_rec for g in got):
-            raise ValueError("exchange_striped_start: shards differ in size (%r records per rank): pass counts=shard_sizes(n, world)" % (got,))
-        _equal_counts_seen.add(key)
-    return [n_rec] * world
+    """counts=None: every rank claims all shards are as long as its own. Verified on EVERY such call by an all_gather of one
+    integer per rank: whether a rank takes part in that collective must not depend on what the rank itself has seen before (a
+    per-rank cache made a step with 334 / 333 / 333 records after an agreed 333 enter the all_gather on rank 0 only). A step
+    loop that wants no collective per step passes counts=."""
+    mine = torch.tensor([n_rec], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    got = [int(t.item()) for t in every]
+    if any(g != n_rec for g in got):
+        raise ValueError("exchange_striped_start: shards differ in size (%r records per rank): pass counts=shard_sizes(n, world)" % (got,))
+    return got
 
 
 def exchange_striped_start(local, record_bytes, group=None, out=None, counts=None):
@@ -92,8 +88,8 @@ def exchange_striped_start(local, record_bytes, group=None, out=None, counts=Non
     `local`: this rank's records as a flat uint8 tensor (a multiple of record_bytes). `counts`: records in EVERY rank's
     shard, in rank order (shard_sizes(n, world) for a batch cut by shard_range: shards differ by one record whenever
     world does not divide n, and a receive posted for the wrong size hangs or truncates over RCCL); None = every shard
-    has as many records as this rank's -- checked against the other ranks' once per distinct size (an all_gather of one
-    integer), so that unequal shards without `counts` raise instead of hanging. Point-to-point, issued as ONE
+    has as many records as this rank's -- checked against the other ranks' on every such call (an all_gather of one
+    integer: every rank enters it, whatever it saw before), so that unequal shards without `counts` raise instead of hanging. Point-to-point, issued as ONE
     batch. Returns (out, works, segments): segments[r] = (begin, end) in bytes of rank r's contribution inside `out`;
     gather_records_wait(works) before touching `out` or overwriting `local`."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1

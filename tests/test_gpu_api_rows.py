@@ -427,6 +427,59 @@ def test_single_process_multi_gpu_context_with_virtual_shards(api, oracle):
         L.rtk_mgpu_destroy(m)
 
 
+def test_striped_exchange_across_real_gpus(api):
+    """rtk_mgpu_trace_rays_device_striped with every slot on a GPU of its own (needs >= 2 GPUs: skipped on the one-GPU box, run by
+    whoever has a node): per-shard records and every stripe on every GPU equal the single-GPU records."""
+    import torch
+    from rtk_amd import shard as shard_py
+    from rtk_amd.types import HIT_RECORD_DTYPE, MeshSet
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("one GPU: the virtual-shard test above covers the code, this one the peer copies")
+    ndev = min(ndev, 4)
+    L = api.lib()
+    tris = synth.scene_for_config(1)
+    devs = (C.c_int * ndev)(*range(ndev))
+    m = L.rtk_mgpu_create(devs, ndev)
+    assert m and L.rtk_mgpu_num_devices(m) == ndev
+    try:
+        ms = MeshSet([dict(positions=tris)])
+        assert L.rtk_mgpu_build(m, C.byref(ms.desc)) == 0, api.last_error()
+        ref = api.DeviceScene.build([dict(positions=tris)])
+        counts = [(1 << 20) + 777 * k for k in range(ndev)]
+        shards = [synth.rays_config1(counts[k], seed=10 + k) for k in range(ndev)]
+        d_rays, d_rec, d_str, seg = [], [], [], [[None] * ndev for _ in range(ndev)]
+        cp = (C.c_size_t * ndev)(*counts)
+        f_, c_ = C.c_size_t(), C.c_size_t()
+        for j in range(ndev):
+            need = 0
+            for r in range(ndev):
+                L.rtk_mgpu_striped_segment(cp, ndev, r, j, C.byref(f_), C.byref(c_))
+                seg[j][r] = (f_.value, c_.value)
+                need = f_.value + c_.value
+            dev = torch.device("cuda", j)
+            d_rays.append(torch.from_numpy(shards[j].view(np.uint8).reshape(-1)).to(dev))
+            d_rec.append(torch.zeros(counts[j] * 16, dtype=torch.uint8, device=dev))
+            d_str.append(torch.full((need * 16,), 0x5a, dtype=torch.uint8, device=dev))
+        for j in range(ndev):
+            torch.cuda.synchronize(j)
+        rp = (C.c_void_p * ndev)(*[t.data_ptr() for t in d_rays])
+        op = (C.c_void_p * ndev)(*[t.data_ptr() for t in d_rec])
+        sp = (C.c_void_p * ndev)(*[t.data_ptr() for t in d_str])
+        plain = api.make_opts()
+        assert L.rtk_mgpu_trace_rays_device_striped(m, rp, cp, op, sp, C.byref(plain)) == 0, api.last_error()
+        for r in range(ndev):
+            w = ref.trace(shards[r], full=False)
+            assert d_rec[r].cpu().numpy().tobytes() == w.tobytes()
+            for j in range(ndev):
+                b, e = shard_py.stripe_bounds(counts[r], ndev)[j]
+                at, ln = seg[j][r]
+                assert ln == e - b
+                assert d_str[j].cpu().numpy()[at * 16:(at + ln) * 16].tobytes() == w[b:e].tobytes()
+    finally:
+        L.rtk_mgpu_destroy(m)
+
+
 def test_filter_rejection_chains_longer_than_one_launch_collects(api, oracle):
     """A stack of 150 parallel triangles: a single ray collects 64 candidates per launch, a 16k-ray batch 4 per
     launch; rejecting the first 100 candidates of every ray needs several rounds and still returns candidate 101,
@@ -648,7 +701,7 @@ def _run_failing_per_ray_calls(n_fail, soft):
     import os
     import subprocess
     import sys
-    env = dict(os.environ)
+    env = dict(os.environ, RTK_AMD_TEST_HOOKS="1")       # the fault-injection hook is a no-op in a process started without this
     env.pop("RTK_AMD_SOFT_ERRORS", None)
     if soft:
         env["RTK_AMD_SOFT_ERRORS"] = "1"
@@ -675,8 +728,71 @@ def test_a_failed_per_ray_call_is_reported_not_passed_off_as_a_miss(api):
     assert p.stderr.count("FAILED, not a miss") == 2
 
 
-def test_single_ray_kernel_equals_the_batch_path(api):
-    """rtk_trace_ray runs a kernel of its own (one wave walks the ray's frontier breadth first, exact nodes, one launch);
+def test_the_fault_injection_hook_is_dead_without_its_environment_switch(api):
+    """rtk_amd_test_fail_next_calls is exported for the test above only: in a process that was not started with
+    RTK_AMD_TEST_HOOKS=1 it does nothing."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "RTK_AMD_TEST_HOOKS"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _FAIL_SNIPPET % root, "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "first False" in p.stdout and "second False" in p.stdout and "FAILED" not in p.stderr
+
+
+def test_per_ray_host_path_equals_the_gpu_batch_path(api):
+    """rtk_trace_ray / rtk_trace_ray_filter are served on the calling thread from the caller's blob (rtk_host_trace.cpp); the batch
+    calls run on the GPU from the device copy of the same blob. Every field of every rtk_hit must agree: a device-built scene
+    (leaves of <= 3 triangles: always the double-precision group) and a CPU-task-builder scene (leaves up to 63: whole groups)."""
+    L = api.lib()
+    tris = synth.triangle_soup(60_000, 0.04, seed=13)
+    rays = np.concatenate([synth.rays_config1(3000, seed=3), synth.rays_incoherent(3000, seed=4)])
+    for builder in (0, 1):
+        L.rtk_amd_set_builder(builder)
+        try:
+            scene, keep = api.build_scene([dict(positions=tris)])
+        finally:
+            L.rtk_amd_set_builder(0)
+        try:
+            hits, mask = api.trace_rays(scene, rays)
+            assert 0.3 < mask.mean() < 1.0
+            for i in range(len(rays)):
+                one = api.trace_ray(scene, rays[i])
+                assert (one is not None) == bool(mask[i]), (builder, i)
+                assert one is None or one.tobytes() == hits[i].tobytes(), (builder, i, one, hits[i])
+            # the host filter loop and the GPU's rounds offer the same candidates in the same order: reject the two closest
+            seen = {}
+
+            def reject_two(i, h):
+                seen[i] = seen.get(i, 0) + 1
+                return seen[i] > 2
+            fh, fm = api.trace_rays_filter(scene, rays[:500], reject_two)
+            FILTER = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_void_p)
+            L.rtk_trace_ray_filter.restype = C.c_bool
+            for i in range(500):
+                count = [0]
+
+                def cb(user, ray_ptr, hit_ptr):
+                    count[0] += 1
+                    return count[0] > 2
+                fn = FILTER(cb)
+                one = np.zeros(1, HIT_DTYPE)
+                ok = L.rtk_trace_ray_filter(C.c_void_p(scene), C.c_void_p(rays[i:i + 1].ctypes.data), C.c_void_p(one.ctypes.data), C.cast(fn, C.c_void_p), None)
+                assert bool(ok) == bool(fm[i]) and (not ok or one[0].tobytes() == fh[i].tobytes()), (builder, i)
+        finally:
+            api.free_scene(scene)
+
+
+@pytest.fixture
+def per_ray_on_gpu(api):
+    api.lib().rtk_amd_set_per_ray(1)
+    yield
+    api.lib().rtk_amd_set_per_ray(0)
+
+
+def test_single_ray_kernel_equals_the_batch_path(api, per_ray_on_gpu):
+    """rtk_amd_set_per_ray(RTK_AMD_PER_RAY_GPU): rtk_trace_ray runs a kernel of its own (one wave walks the ray's frontier breadth first, exact nodes, one launch);
     every field of its rtk_hit must be what the batch call returns for the same ray -- ordinary rays, exotic ones (zeros,
     infinities, NaN intervals: the reference's operand order decides), a scene where one ray meets thousands of boxes (the
     frontier does not fit LDS: the call falls back to the batch path), an empty scene."""

@@ -195,3 +195,29 @@ def test_bench_multi_rank_plumbing_dry_run():
     k = d["config"]["per_rank_kernel_ms"]
     assert len(k["per_rank"]) == 2 and k["min"] <= k["max"]
     assert set(d["config"]["exposed_exchange_ms_per_step"]) == {"striped", "root"}
+
+
+def test_bench_starts_its_own_ranks_when_called_bare():
+    """The driver's command form is `python bench.py --gpus N`: without WORLD_SIZE in the environment bench.py must start the N
+    ranks itself (a child torch.distributed.run; the parent never touches a GPU) and relay rank 0's one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu",
+                        "--frame", "64"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "dry-run" in d["data"]
+    assert "cpu_baseline" not in d
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """--gpus N under a launcher with another WORLD_SIZE: an error exit, never a line for the wrong number of GPUs."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run-cpu",
+                        "--frame", "64"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
