@@ -115,6 +115,41 @@ def limiter_from_pmc(pj):
     return out
 
 
+FRAC_NOTE = ("the ALGORITHMIC bytes (every visit priced at its record size, SURVEY.md 8d) divided by the kernel's time exceed the 8 TB/s "
+             "HBM peak: the caches serve most of them (see limiter.l2_hit_rate), so that quotient is cache demand and NOT a fraction of "
+             "the HBM roofline -- `frac` is null; `real_bound` names what the counters say binds the kernel, `frac_by_traffic` is "
+             "the measured fabric traffic over the same time")
+
+
+def honest_fractions(achieved_gbs, traffic, k_ms, lim):
+    """(frac, frac_note, frac_by_traffic, real_bound). `frac` is achieved / peak only while that is a statement about HBM
+    (<= 1); `real_bound` lists every ceiling the committed counters can price -- fabric traffic against the HBM peak, VALU
+    issue slots (busy share of the four SIMDs' pipes; times the lane utilisation = useful lane-operations against the chip's
+    VALU peak), the CU's scalar issue port, L2 misses per second against the 56 G/s the memory system gave a pure gather
+    kernel -- and names the largest."""
+    over = achieved_gbs > HBM_PEAK_GBS
+    frac = None if over else round(achieved_gbs / HBM_PEAK_GBS, 4)
+    fbt = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
+    real = None
+    if lim:
+        c = {}
+        if fbt is not None:
+            c["hbm_traffic_of_8_TB_s"] = fbt
+        if lim.get("valu_busy") is not None:
+            c["valu_issue_slots"] = lim["valu_busy"]
+            if lim.get("valu_lane_utilisation") is not None:
+                c["valu_lane_ops_of_peak"] = round(lim["valu_busy"] * lim["valu_lane_utilisation"], 3)
+        if lim.get("salu_issue") is not None:
+            c["scalar_issue_port"] = lim["salu_issue"]
+        if lim.get("l2_miss_g_per_s") is not None:
+            c["l2_misses_of_56_G_s"] = round(lim["l2_miss_g_per_s"] / L2_MISS_CEILING_G_PER_S, 3)
+        binding = [k for k in c if k != "valu_lane_ops_of_peak"]
+        if binding:
+            top = max(binding, key=lambda k: c[k])
+            real = dict(c, binding=top, binding_frac=c[top])
+    return frac, (FRAC_NOTE if over else None), fbt, real
+
+
 def f32_ulps(a, b):
     return int(abs(int(np.float32(a).view(np.int32)) - int(np.float32(b).view(np.int32))))
 
@@ -224,12 +259,13 @@ def other_workload(kind, steps, warmup, frame=4096, with_parity=True):
     from rtk_amd import api as _api
     _api.lib().rtk_amd_release_workspace()
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    frac, frac_note, fbt, real_bound = honest_fractions(achieved, traffic, k_ms, lim)
     return {"workload": ("config5: 10M-tri soup, GPU LBVH build + %d any-hit shadow rays (re-ordered by entry cell inside every step)" % n) if shadow
             else ("config3: 1M-tri soup, %d incoherent rays (re-ordered by entry cell inside every step)" % n),
             "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "kernel_ms": round(k_ms, 4),
             "hit_fraction": round(hit_frac, 4), "bvh_build_ms_device_resident_mesh": round(build_ms, 3),
-            "algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gb_s": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "frac_by_traffic": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gb_s": round(achieved, 1), "frac": frac, "frac_note": frac_note,
+            "frac_by_traffic": fbt, "real_bound": real_bound,
             "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "triangles": round(ctr["triangles"] / n, 2)},
             "traffic": traffic, "traffic_source": src if traffic else ("none: %s was measured on other kernel code" % src if pj else None),
             "limiter": {k: v for k, v in lim.items()} if lim else None,
@@ -590,6 +626,7 @@ def main():
     mrays = total_rays / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    h_frac, h_note, h_fbt, h_real = honest_fractions(achieved, traffic, k_ms, limiter)
     lane_asm = os.environ.get("RTK_AMD_LANE_ASM", "1") != "0" and lane_node_bytes == 64 and not args.static
     beam = os.environ.get("RTK_AMD_PACKET_BEAM", "2")
     kernel_name = ({"0": "rtk_packet_hot", "1": "rtk_packet_beam"}.get(beam, "rtk_packet_beam2") + " (hand-written gfx950 assembly) + rtk_trace_packet_kernel<false> on the tiles it hands back" if packet_kernel else
@@ -629,10 +666,7 @@ def main():
                    "ray_order": "RTK_TRACE_SORT_RAYS: re-ordered by origin cell inside every timed step" if args.sort_rays else "as given",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "frac_by_traffic": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                     "frac_note": ("`frac` prices the ALGORITHMIC bytes (what the unit of work fetches by SURVEY.md 8d) at the kernel's time; above 1 "
-                                   "it says that the caches serve part of them -- `frac_by_traffic` is the measured fabric traffic over the same time") if achieved > HBM_PEAK_GBS else None,
+                     "frac": h_frac, "traffic": traffic, "frac_by_traffic": h_fbt, "frac_note": h_note, "real_bound": h_real,
                      "traffic_unit": ("bytes per launch of the traversal kernel crossing the L2 -> fabric boundary, Infinity-Cache (MALL) hits "
                                       "INCLUDED: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 PMC passes, %s; the scene is %.0f MB (the MALL "
                                       "holds 256 MiB), so this is %s" % (traffic_src, info.get("total_device_bytes", 0) / 1e6,

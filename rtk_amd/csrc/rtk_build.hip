@@ -613,7 +613,8 @@ struct Climb { int cur_ref; int l; int r; };      // cur_ref: >= 0 inner node, <
 __device__ __forceinline__ unsigned long long meet_word(int ref, int end) { return (((unsigned long long)(uint32_t)ref << 32) | (uint32_t)end) + 1ull; }
 
 __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
-	BinNode *bin, Climb *climbers, unsigned long long *meet, int *climb_idx, uint32_t *tile_nclimb, int *root, BuildParams bp, float *area)
+	BinNode *bin, Climb *climbers, unsigned long long *meet, int *climb_idx, uint32_t *tile_nclimb, int *root, BuildParams bp, float *area,
+	uint32_t *equal_codes)
 {
 	__shared__ uint32_t s_nclimb;
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
@@ -627,8 +628,16 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	s_arrive[t] = 0u;
 	if (t == 0) s_nclimb = 0u;
 	s_lr[t] = make_int2(INT_MIN, INT_MIN);
-	if (lo + t - 1 <= hi) s_delta[t] = key_delta(keys, n, lo + t - 1);
+	int my_delta = -1;
+	if (lo + t - 1 <= hi) s_delta[t] = my_delta = key_delta(keys, n, lo + t - 1);
 	if (t == 0 && hi - lo + 1 == REFIT_TILE) s_delta[REFIT_TILE] = key_delta(keys, n, hi);
+	{
+		// how many neighbours in sorted order share their whole Morton code (a common prefix of 40 bits or more: the packed
+		// words carry the code above a 24-bit index, equal pair keys count 64+): where that is common the key was too narrow for
+		// the scene -- a dense mesh in a corner of the scene box -- and the host builds again with the full 40 bits
+		const unsigned long long same = __ballot(t > 0 && my_delta >= 40);
+		if ((t & 63) == 0 && same) atomicAdd(equal_codes, (uint32_t)__popcll(same));
+	}
 	__syncthreads();
 	const int i = lo + t;
 	Climb left_over;
@@ -1609,8 +1618,11 @@ extern "C" void rtk_amd_release_workspace(void)
 	}
 }
 
-extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
+// force_bits: 0 = key width from the number of triangles; else the width of the Morton code in the packed sort words.
+// *narrow_key: the build was made with fewer than 40 bits and more than an eighth of the sorted neighbours share their code.
+static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits, bool *narrow_key)
 {
+	*narrow_key = false;
 	if (!desc || (!desc->meshes && desc->num_meshes)) { rtk_set_error("rtk_dev_scene_build: NULL scene description"); return nullptr; }
 	std::vector<uint64_t> mesh_base(desc->num_meshes + 1, 0);
 	for (size_t m = 0; m < desc->num_meshes; m++) mesh_base[m + 1] = mesh_base[m] + desc->meshes[m].num_triangles;
@@ -1809,6 +1821,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		packed_bits = ((lg + 8u + 7u) / 8u) * 8u;
 		if (packed_bits < 24u) packed_bits = 24u;
 		if (packed_bits > 40u) packed_bits = 40u;
+		if (force_bits) packed_bits = force_bits;
 		if (getenv("RTK_AMD_KEY_BITS")) { const int kb = atoi(getenv("RTK_AMD_KEY_BITS")); if (kb >= 8 && kb <= 40 && kb % 8 == 0) packed_bits = (uint32_t)kb; }
 	}
 	uint32_t *vals_a = packed ? nullptr : ar.take<uint32_t>(n), *vals_b = packed ? nullptr : ar.take<uint32_t>(n);
@@ -1905,7 +1918,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	if (hipMemsetAsync(d_half, 0, (size_t)n * 8, bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
 	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
-		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area);
+		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area, d_depth_word + 1);
 	hipLaunchKernelGGL(k_refit_top, dim3(num_tiles), dim3(64), 0, bs, d_tris, (int)n, keys, d_climbers, d_climb_idx, d_tile_nclimb, d_half, d_bin, d_lr, d_range,
 		d_root, bp, tile_mode);
 	if (tile_mode) {
@@ -1977,6 +1990,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		}
 	};
 	uint32_t total_nodes = 0, depth = 0;
+	uint32_t h_equal_codes = 0;          // sorted neighbours with one and the same Morton code (counted by k_refit_tile)
 	if (tile_mode) {
 		if (rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();             // (the callee's error text stands)
 		DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
@@ -1996,6 +2010,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 			if (hipGetLastError() != hipSuccess ||
 				hipMemcpyAsync(&h_tail[0], d_tile_base + num_tiles, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipMemcpyAsync(&h_tail[1], d_depth_word, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
+				hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipStreamSynchronize(bs) != hipSuccess) return fail("tile collapse");
 			if (timing) {
 				std::vector<uint32_t> hc(num_tiles + 1), hb(num_tiles + 1);
@@ -2019,7 +2034,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 			node_cap = total_nodes;
 			if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
 			ds->allocs.push_back(node_mem);
-			if (hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
+			if (hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 4, bs) != hipSuccess) return fail("memset");
 		}
 		stage("collapse");
 	} else {
@@ -2046,6 +2061,7 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap)) != RTK_AMD_OK) return give_up();
 	}
 	ds->total_bytes += node_cap * (sizeof(DevNode) + sizeof(DevNodeQ));
+	if (!tile_mode && hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess) return fail("copy");
 	if (hipStreamSynchronize(bs) != hipSuccess || (side_busy && hipStreamSynchronize(ws.side) != hipSuccess)) return fail("sync");   // the workspace is handed back below
 	rtk_quantize_finish(ds);
 
@@ -2061,11 +2077,32 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	ds->stack_entries = 3u * depth + 1u;
 	stage("finish");
 	ds->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+	*narrow_key = packed && packed_bits < 40u && (uint64_t)h_equal_codes * 8u > (uint64_t)n;
+	if (timing) fprintf(stderr, "rtk_amd build: %u key bits, %u of %u sorted neighbours share a code%s\n", packed ? packed_bits : key_bits, h_equal_codes, n,
+		*narrow_key ? " -> key too narrow for this scene" : "");
 	if (getenv("RTK_AMD_KEEP_WORKSPACE") && atoi(getenv("RTK_AMD_KEEP_WORKSPACE")) == 0) {
 		(void)hipFree(ws.base);
 		ws.base = nullptr;
 		ws.cap = 0;
 	}
+	return ds;
+}
+
+// The key width follows the NUMBER of triangles (ceil(log2 n) + 8 bits of the 63-bit code: four radix passes up to 2^24
+// triangles), which assumes they are spread over the scene box. Where they are not -- a dense mesh in 1 % of the box --
+// hundreds of triangles share a cell, their order inside it is the order of their numbers, and the SAH decisions of the refit
+// cannot repair that topology. k_refit_tile counts the sorted neighbours with equal codes while it builds the
+// tree; if more than an eighth of them are equal the scene is built once more with the full 40 bits: twice the time for such a
+// scene, the same tree quality as before the narrow keys, nothing for scenes that do not need it.
+extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
+{
+	bool narrow = false;
+	rtk_dev_scene *ds = build_impl(desc, 0u, &narrow);
+	if (!ds || !narrow || (getenv("RTK_AMD_KEY_REBUILD") && atoi(getenv("RTK_AMD_KEY_REBUILD")) == 0)) return ds;
+	const double first_ms = ds->build_ms;
+	rtk_dev_scene_free(ds);
+	ds = build_impl(desc, 40u, &narrow);
+	if (ds) ds->build_ms += first_ms;
 	return ds;
 }
 

@@ -150,3 +150,37 @@ def test_near_tie_rays_are_reference_answers(api, oracle, scene, golden_dir):
     _check_near_ties(g, "cfg2", full[idx], "cfg2 packet")
     # the fixture is not vacuous: the device BVH does resolve some of these ties the other way than the CPU's SAH tree
     assert seconds >= 1
+
+
+def test_shadow_full_batch(api, oracle):
+    """Config 5 at BASELINE.json's full size: the 10M-triangle scene built on the GPU, all 2^24 shadow rays. Properties that do not
+    depend on the size: the any-hit flag of every ray equals the closest-hit boolean of an independent kernel on the same scene;
+    every closest hit lies on its triangle inside the ray's open interval; the flags do not depend on the launch mode (given
+    order / re-ordered by entry cell / exact nodes); a strided 2^16-ray sample equals the CPU oracle traversing the exported
+    BVH (the flag == its closest-hit boolean)."""
+    import torch
+    cfg = synth.CONFIGS[5]
+    d_tris = synth.t_triangle_soup(cfg["num_tris"], cfg["spread"], cfg["scene_seed"])
+    ds = api.DeviceScene.build([dict(positions=d_tris)])
+    assert ds.info()["num_triangles"] == 10_000_000
+    tris = d_tris.cpu().numpy()
+    del d_tris
+    rays = synth.t_rays_shadow(N).cpu().numpy().view(synth.rays_shadow(1).dtype).reshape(-1)
+    assert rays[:4096].tobytes() == synth.rays_shadow(4096).tobytes()          # the device generator is the host generator
+    occ = ds.trace_any(rays).astype(bool)
+    assert 0.3 < occ.mean() < 0.99
+    assert (ds.trace_any(rays, opts=api.make_opts(sort_rays=True)).astype(bool) == occ).all()
+    assert (ds.trace_any(rays, opts=api.make_opts(exact_nodes=True)).astype(bool) == occ).all()
+    rec = ds.trace(rays, opts=api.make_opts(sort_rays=True), full=False)
+    assert ((rec["prim"] != 0xFFFFFFFF) == occ).all()
+    nhit = _check_geometry(tris, rays, rec)
+    assert nhit == int(occ.sum())
+    blob = oracle.Blob(ds.export_blob())
+    sel = np.arange(0, N, 256)
+    oh, om = oracle.trace(blob, np.ascontiguousarray(rays[sel]))
+    assert (occ[sel] == om).all()
+    g = rec[sel]
+    assert (g["prim"][om] == oh["triangle_index"][om]).all()
+    assert (g["t"][om] == oh["t"][om]).all() and (g["u"][om] == oh["u"][om]).all() and (g["v"][om] == oh["v"][om]).all()
+    ds.free()
+    torch.cuda.empty_cache()
