@@ -551,7 +551,27 @@ static void trace_packet_pair(const std::vector<Ray> &rs, PairCnt &c, const std:
 // PK_TILEBEAM == 20: one wave walks TWO adjacent 8x8 tiles (a 16x8-pixel tile as two ray groups with a beam each: lanes 0-31 / 32-63 of
 // the plane-per-lane layout test the same node for the two groups): an entry carries the set of groups that enter it; a triangle is
 // tested only for the groups whose own beam reaches its leaf. Counts per 128 rays: node steps, triangle tests per group.
-struct GrpCnt { uint64_t tiles = 0, node_steps = 0, tri_group_tests = 0, leaves = 0, pushes = 0, pops = 0, culled = 0; };
+struct GrpCnt { uint64_t tiles = 0, node_steps = 0, tri_group_tests = 0, leaves = 0, pushes = 0, pops = 0, culled = 0, t_geom = 0, t_acc = 0, t_edge = 0, t_edge_wrong = 0, t_far = 0; };
+// Round 5: would a wave-uniform test of the triangle against the GROUP's beam have skipped this triangle test? Common origin: the edge
+// function of edge k for a ray of direction d is n_k . d (n_k = p_(k+1) x p_(k+2), p = vertex - origin), linear in d, so its range over
+// the group's direction box is the sum of the per-component extremes. Skipped if some edge function is negative for every ray of the
+// box and another one positive for every ray (then the signs are mixed for every ray: rtk.c:340-344), with a relative margin.
+static bool edge_cull(const std::vector<Ray> &g, const float *p) {
+	double dlo[3] = { 1e30, 1e30, 1e30 }, dhi[3] = { -1e30, -1e30, -1e30 };
+	for (const Ray &r : g) for (int a = 0; a < 3; a++) { dlo[a] = std::min(dlo[a], (double)r.d[a]); dhi[a] = std::max(dhi[a], (double)r.d[a]); }
+	double q[3][3]; for (int v = 0; v < 3; v++) for (int a = 0; a < 3; a++) q[v][a] = (double)p[3 * v + a] - g[0].o[a];
+	bool neg = false, pos = false;
+	for (int k = 0; k < 3; k++) {
+		const double *a = q[(k + 1) % 3], *b = q[(k + 2) % 3];
+		const double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+		double mx = 0, mn = 0, mag = 0;
+		for (int c = 0; c < 3; c++) { mx += std::max(n[c] * dlo[c], n[c] * dhi[c]); mn += std::min(n[c] * dlo[c], n[c] * dhi[c]); mag += std::max(std::fabs(n[c] * dlo[c]), std::fabs(n[c] * dhi[c])); }
+		const double m = mag * (1.0 / 4096.0);
+		if (mx < -m) neg = true;
+		if (mn > m) pos = true;
+	}
+	return neg && pos;
+}
 static void trace_packet_groups(const std::vector<Ray> &rs, int tw, GrpCnt &c, const std::vector<PkEntry> *entries, std::vector<float> *tout) {
 	const int L = (int)rs.size();
 	std::vector<float> best(L); for (int i = 0; i < L; i++) best[i] = rs[i].tmax;
@@ -577,7 +597,13 @@ static void trace_packet_groups(const std::vector<Ray> &rs, int tw, GrpCnt &c, c
 		if (!gm) { c.culled++; continue; }
 		if (e.ref < 0) {
 			const Leaf &l = leaves[~e.ref]; c.leaves++;
-			for (uint32_t p : l.prims) for (int q = 0; q < 2; q++) if (gm & (1 << q)) { c.tri_group_tests++; for (int i : gi[q]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t) && t > rs[i].tmin && t < best[i]) best[i] = (float)t; } }
+			for (uint32_t p : l.prims) for (int q = 0; q < 2; q++) if (gm & (1 << q)) {
+				c.tri_group_tests++;
+				bool geom = false, acc = false; double tnear = 1e30;
+				for (int i : gi[q]) { double t; if (tri_hit(rs[i], &tris[9 * (size_t)p], t)) { geom = true; tnear = std::min(tnear, t); if (t > rs[i].tmin && t < best[i]) { best[i] = (float)t; acc = true; } } }
+				const bool ec = edge_cull(g[q], &tris[9 * (size_t)p]);
+				c.t_geom += geom; c.t_acc += acc; c.t_edge += ec; c.t_edge_wrong += ec && geom; c.t_far += geom && !acc;
+			}
 			continue;
 		}
 		c.node_steps++;
@@ -638,9 +664,11 @@ static void packet_lab(int W_, int H_, int nblocks) {
 			cnh += cache.nh; cnm += cache.nm; cth += cache.th; ctm += cache.tm;
 		}
 #pragma omp critical
-		{ gc.tiles += lgc.tiles; gc.node_steps += lgc.node_steps; gc.tri_group_tests += lgc.tri_group_tests; gc.leaves += lgc.leaves; gc.pushes += lgc.pushes; gc.pops += lgc.pops; gc.culled += lgc.culled; gnh += cnh; gnm += cnm; gth += cth; gtm += ctm; pc.tiles += lpc.tiles; pc.node_rounds += lpc.node_rounds; pc.nodes_tested += lpc.nodes_tested; pc.tri_steps += lpc.tri_steps; pc.leaf_rounds += lpc.leaf_rounds; pc.pushes += lpc.pushes; pc.pops += lpc.pops; pc.culled += lpc.culled; c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
+		{ gc.tiles += lgc.tiles; gc.node_steps += lgc.node_steps; gc.tri_group_tests += lgc.tri_group_tests; gc.leaves += lgc.leaves; gc.pushes += lgc.pushes; gc.pops += lgc.pops; gc.culled += lgc.culled; gc.t_geom += lgc.t_geom; gc.t_acc += lgc.t_acc; gc.t_edge += lgc.t_edge; gc.t_edge_wrong += lgc.t_edge_wrong; gc.t_far += lgc.t_far; gnh += cnh; gnm += cnm; gth += cth; gtm += ctm; pc.tiles += lpc.tiles; pc.node_rounds += lpc.node_rounds; pc.nodes_tested += lpc.nodes_tested; pc.tri_steps += lpc.tri_steps; pc.leaf_rounds += lpc.leaf_rounds; pc.pushes += lpc.pushes; pc.pops += lpc.pops; pc.culled += lpc.culled; c.tiles += lc.tiles; for (int k = 0; k < 5; k++) c.steps[k] += lc.steps[k]; c.pops += lc.pops; c.pops_culled += lc.pops_culled; c.tri_steps += lc.tri_steps; c.pushes += lc.pushes;
 		  c.lane_nodes += lc.lane_nodes; c.entries += lc.entries; c.entry_culled += lc.entry_culled; c.pre_steps += lc.pre_steps; c.blocks += lc.blocks; c.entry_list += lc.entry_list; tsum += ls; mism += lm; }
 	}
+	if (PK_TILEBEAM == 20) printf("  of the triangle tests per group: %.1f %% meet a ray geometrically, %.1f %% are accepted by a ray, %.1f %% met but behind every hit; the beam's edge test would skip %.1f %% (wrongly: %llu)\n",
+		100.0 * gc.t_geom / gc.tri_group_tests, 100.0 * gc.t_acc / gc.tri_group_tests, 100.0 * gc.t_far / gc.tri_group_tests, 100.0 * gc.t_edge / gc.tri_group_tests, (unsigned long long)gc.t_edge_wrong);
 	if (PK_TILEBEAM == 20) { const double T3 = (double)gc.tiles; printf("  two ray groups per wave (%d lanes): per tile: node steps %.2f leaves %.2f triangle tests per group %.2f pushes %.2f pops %.2f (culled %.2f) | t mismatches %llu\n", PK_LANES, gc.node_steps / T3, gc.leaves / T3, gc.tri_group_tests / T3, gc.pushes / T3, gc.pops / T3, gc.culled / T3, (unsigned long long)mism); return; }
 	if (PK_TILEBEAM >= 2) { const double T2 = (double)pc.tiles; printf("  beam, %d nodes per round: per tile: node rounds %.2f (nodes tested %.2f) leaf rounds %.2f tri steps %.2f pushes %.2f pops %.2f (culled %.2f) | t mismatches %llu\n", PK_TILEBEAM, pc.node_rounds / T2, pc.nodes_tested / T2, pc.leaf_rounds / T2, pc.tri_steps / T2, pc.pushes / T2, pc.pops / T2, pc.culled / T2, (unsigned long long)mism); return; }
 	const double T = (double)c.tiles; const uint64_t st = c.steps[0] + c.steps[1] + c.steps[2] + c.steps[3] + c.steps[4];

