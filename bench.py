@@ -396,6 +396,9 @@ def main():
 
         trace_any_counted = trace_counted
 
+        def trace_packet_counted(self, rays, opts):
+            return None, None
+
     t0 = time.time()
     tris = None if DRY else synth.triangle_soup(cfg["num_tris"], cfg["spread"], cfg["scene_seed"])
     t_gen = time.time() - t0
@@ -516,12 +519,27 @@ def main():
     # the per-lane kernels read the 64-byte compressed nodes (DevNodeQ) unless RTK_AMD_QNODES=0, the packet kernel the 128-byte exact ones
     lane_node_bytes = NODE_BYTES if os.environ.get("RTK_AMD_QNODES", "1") == "0" else 64
     per_ray_bytes = n * (RAY_BYTES + out_bytes) + ctr["nodes"] * (NODE_BYTES if packet_kernel else lane_node_bytes) + ctr["triangles"] * TRI_BYTES
+    pk_ctr = None
     if packet_kernel:
+        # the counting form of the kernel that is TIMED: rtk_packet_count2 = rtk_packet_beam2.S assembled with -DRTK_COUNT (three scalar
+        # counters per pair of tiles), plus the counting build of the C++ packet kernel on the tiles it hands back
+        try:
+            _, pk_ctr = ds.trace_packet_counted(rays, opts)
+        except api.RtkError as e:
+            log("packet counters not available (%s): pricing the C++ packet kernel's steps" % e)
+    if packet_kernel and pk_ctr:
+        fetched_nodes = pk_ctr["node_steps"] + pk_ctr["handed_back_node_steps"]
+        fetched_tris = pk_ctr["triangles_fetched"] + pk_ctr["handed_back_triangle_steps"]
+        ENTRY_RECORD_BYTES = 64 + 256 + 1536      # what a pair reads of its block's PkBlockEntries: header, 64 reference words, 24 planes x 16 virtual nodes
+        alg_bytes = n * (RAY_BYTES + out_bytes) + fetched_nodes * NODE_BYTES + fetched_tris * TRI_BYTES + pk_ctr["entry_records"] * ENTRY_RECORD_BYTES
+        unit = ("PAIR of adjacent 8x8-pixel tiles (128 rays, one wave): 32 B per ray in, 16 B per ray out, each node (128 B) priced once per node "
+                "step of the pair, each triangle record (48 B) once per triangle of a leaf the pair enters, 1856 B of its block's entry record; steps counted by rtk_packet_count2, "
+                "the kernel that is timed assembled with -DRTK_COUNT (rtk_dev_trace_rays_packet_counted), plus the C++ packet kernel's own "
+                "counting build on the %d tiles handed back" % pk_ctr["tiles_handed_back"])
+    elif packet_kernel:
         alg_bytes = n * (RAY_BYTES + out_bytes) + ctr["wave_node_steps"] * NODE_BYTES + ctr["wave_triangle_steps"] * TRI_BYTES
         unit = ("tile of 64 rays: each node (128 B) and triangle (48 B) priced once per tile; visit and step counts are those of the counting "
-                "C++ kernel (per-lane slab tests, one tile per wave). The kernel that runs (rtk_packet_beam2) walks two adjacent tiles per wave "
-                "with the interval test of their beams: 33.5 node steps per PAIR of tiles instead of 2 x 26.2, the same triangle tests "
-                "(scripts/bvh_lab.cpp -tb 20) -- it fetches fewer bytes than this model prices")
+                "C++ kernel (per-lane slab tests, one tile per wave)")
     else:
         alg_bytes = per_ray_bytes
         unit = "ray: each lane fetches its own nodes (%d B) and triangles (48 B)" % lane_node_bytes
@@ -686,7 +704,14 @@ def main():
                      "visits_per_ray": {"nodes": round(ctr["nodes"] / n, 2), "leaves": round(ctr["leaves"] / n, 2),
                                         "triangles": round(ctr["triangles"] / n, 2)},
                      "wave_steps_per_64_rays": {"nodes": round(ctr["wave_node_steps"] * 64.0 / n, 1),
-                                                "triangles": round(ctr["wave_triangle_steps"] * 64.0 / n, 1)},
+                                                "triangles": round(ctr["wave_triangle_steps"] * 64.0 / n, 1),
+                                                "of": "rtk_trace_packet_kernel<true> (C++, one tile per wave, per-lane slab tests)" if packet_kernel else "the counting build of the per-lane kernel"},
+                     "timed_kernel_steps": ({"per_pair_of_tiles": {"node_steps": round(pk_ctr["node_steps"] / max(1, pk_ctr["pairs"]), 2),
+                                                                  "triangles_fetched": round(pk_ctr["triangles_fetched"] / max(1, pk_ctr["pairs"]), 2),
+                                                                  "triangle_group_tests": round(pk_ctr["triangle_group_tests"] / max(1, pk_ctr["pairs"]), 2)},
+                                             "pairs": pk_ctr["pairs"], "entry_records_taken": pk_ctr["entry_records"], "tiles_handed_back": pk_ctr["tiles_handed_back"],
+                                             "handed_back_node_steps": pk_ctr["handed_back_node_steps"], "handed_back_triangle_steps": pk_ctr["handed_back_triangle_steps"],
+                                             "counted_by": "rtk_packet_count2 (rtk_packet_beam2.S -DRTK_COUNT)"} if pk_ctr else None),
                      "per_ray_model": {"bytes_per_ray": round(per_ray_bytes / n, 1), "gb_s": round(per_ray_bytes / (k_ms * 1e-3) / 1e9, 1),
                                        "note": "every lane's visit priced at full size; caches absorb these for coherent rays, so this is "
                                                "cache bandwidth demand, not a fraction of the HBM roofline"},

@@ -209,6 +209,24 @@ int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, s
 int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, rtk_trace_counters *out);
 
+/* Step counts of the hand-written packet kernel ITSELF: the launch runs rtk_packet_count2, which is rtk_packet_beam2.S assembled
+ * with three scalar counters per pair of tiles ("visit counts come from a counting build of the same kernel"), and
+ * the counting build of the C++ packet kernel on the tiles it hands back. Same records as rtk_dev_trace_rays. Synchronous; not
+ * for timing. RTK_AMD_ERR_UNSUPPORTED if the batch would not run on rtk_packet_beam2 (no image hint, big leaves, ...). */
+typedef struct rtk_packet_counters {
+	uint64_t tiles;                      /* 8x8-pixel tiles of the batch (n / 64) */
+	uint64_t pairs;                      /* pairs of tiles walked by a wave (handed-back pairs included, with the steps they took until then) */
+	uint64_t node_steps;                 /* 128 B nodes fetched: one per node step of a PAIR */
+	uint64_t triangles_fetched;          /* 48 B triangle records fetched: one per triangle of a leaf a pair enters */
+	uint64_t triangle_group_tests;       /* triangle tests: one per (triangle, group of 64 rays whose beam reaches the leaf) */
+	uint64_t tiles_handed_back;          /* tiles traced again from the start by the C++ packet kernel */
+	uint64_t handed_back_node_steps;     /* ... its wave-level node steps (one tile per wave) */
+	uint64_t handed_back_triangle_steps; /* ... and triangle steps */
+	uint64_t entry_records;              /* pairs that took their block's entry record (64 B header + 256 B of references + 1536 B of entry boxes) */
+} rtk_packet_counters;
+int rtk_dev_trace_rays_packet_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_packet_counters *out);
+
 /* -- several GPUs of one node, one process --
  * Rays shard, nothing else: the scene is replicated (the deterministic build or the upload runs on every GPU),
  * shard r of R owns the contiguous range rtk_amd_shard_range(n, r, R) of the batch, and the only exchange is the

@@ -70,6 +70,16 @@ class TraceCounters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class PacketCounters(C.Structure):
+    """rtk_packet_counters: step counts of rtk_packet_count2 (the counting form of rtk_packet_beam2)."""
+    _fields_ = [("tiles", C.c_uint64), ("pairs", C.c_uint64), ("node_steps", C.c_uint64), ("triangles_fetched", C.c_uint64),
+                ("triangle_group_tests", C.c_uint64), ("tiles_handed_back", C.c_uint64),
+                ("handed_back_node_steps", C.c_uint64), ("handed_back_triangle_steps", C.c_uint64), ("entry_records", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 # every symbol include/rtk.h and include/rtk_amd.h declare
 RTK_H_SYMBOLS = ["rtk_start_build", "rtk_run_task", "rtk_get_build_size", "rtk_finish_build_to",
                  "rtk_finish_build", "rtk_build_scene", "rtk_free_scene", "rtk_trace_ray", "rtk_trace_ray_filter"]
@@ -77,7 +87,7 @@ RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_
                      "rtk_dev_scene_upload", "rtk_dev_scene_build", "rtk_dev_scene_free", "rtk_dev_scene_get_info",
                      "rtk_dev_scene_mesh_base", "rtk_dev_scene_primitive_order", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
                      "rtk_dev_trace_rays", "rtk_dev_trace_rays_any", "rtk_dev_expand_hits",
-                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_trace_rays", "rtk_amd_forget_scene",
+                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_dev_trace_rays_packet_counted", "rtk_trace_rays", "rtk_amd_forget_scene",
                      "rtk_dev_scene_validate", "rtk_amd_release_workspace", "rtk_dev_scene_upload_buffer",
                      "rtk_dev_trace_rays_filtered", "rtk_dev_trace_rays_any_filtered", "rtk_dev_trace_status",
                      "rtk_trace_rays_filter", "rtk_amd_shard_range", "rtk_mgpu_create", "rtk_mgpu_destroy", "rtk_mgpu_num_devices",
@@ -119,6 +129,7 @@ def lib():
     L.rtk_dev_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts), C.c_void_p]
     L.rtk_dev_trace_rays_any.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts), C.c_void_p]
     L.rtk_dev_expand_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtk_dev_trace_rays_packet_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts), C.POINTER(PacketCounters)]
     L.rtk_dev_trace_rays_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts),
                                              C.POINTER(TraceCounters)]
     L.rtk_dev_trace_rays_any_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(TraceOpts),
@@ -422,6 +433,24 @@ class DeviceScene:
         _check(lib().rtk_dev_trace_rays_counted(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_rec.data_ptr()),
                                                 C.byref(opts) if opts is not None else None, C.byref(ctr)),
                "rtk_dev_trace_rays_counted")
+        return d_rec.cpu().numpy().view(HIT_RECORD_DTYPE), ctr.as_dict()
+
+
+    def trace_packet_counted(self, rays, opts):
+        """rtk_dev_trace_rays_packet_counted: (records, counters of the hand-written packet kernel itself)."""
+        torch = _torch()
+        if hasattr(rays, "data_ptr"):
+            d_rays, n = rays, rays.numel() * rays.element_size() // 32
+        else:
+            rays = np.ascontiguousarray(rays)
+            n = rays.shape[0]
+            d_rays = to_device(rays)
+        d_rec = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+        ctr = PacketCounters()
+        torch.cuda.synchronize()
+        _check(lib().rtk_dev_trace_rays_packet_counted(self.handle, C.c_void_p(d_rays.data_ptr()), n, C.c_void_p(d_rec.data_ptr()),
+                                                       C.byref(opts) if opts is not None else None, C.byref(ctr)),
+               "rtk_dev_trace_rays_packet_counted")
         return d_rec.cpu().numpy().view(HIT_RECORD_DTYPE), ctr.as_dict()
 
 

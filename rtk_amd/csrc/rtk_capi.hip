@@ -147,6 +147,13 @@ extern "C" int rtk_dev_trace_rays_any_counted(const rtk_dev_scene *ds, const rtk
 	return rtk_launch_trace(ds, d_rays, n, nullptr, d_occluded, opts, nullptr, true, out);
 }
 
+extern "C" int rtk_dev_trace_rays_packet_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
+	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_packet_counters *out)
+{
+	if (!out) { rtk_set_error("rtk_dev_trace_rays_packet_counted: NULL counters"); return RTK_AMD_ERR_BAD_ARG; }
+	return rtk_launch_trace(ds, d_rays, n, d_hits, nullptr, opts, nullptr, false, nullptr, nullptr, nullptr, nullptr, 0, out);
+}
+
 extern "C" int rtk_dev_trace_status(const rtk_dev_scene *ds, void *stream)
 {
 	return rtk_trace_status(ds, (hipStream_t)stream);

@@ -183,7 +183,8 @@ bool rtk_sort_words_async(unsigned long long *keys_a, unsigned long long *keys_b
 // -- trace launches (rtk_trace.hip) --
 int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
-	const rtk_dev_filter *filter = nullptr, rtk_hit_record *d_cand = nullptr, uint32_t *d_cand_count = nullptr, uint32_t cand_k = 0);
+	const rtk_dev_filter *filter = nullptr, rtk_hit_record *d_cand = nullptr, uint32_t *d_cand_count = nullptr, uint32_t cand_k = 0,
+	rtk_packet_counters *pk_counted = nullptr);
 int rtk_trace_status(const rtk_dev_scene *ds, hipStream_t stream);
 void rtk_scratch_free(LaunchScratch *s);
 void rtk_scene_drop_stream(rtk_dev_scene *ds, hipStream_t stream);   // the stream is about to be destroyed (and has been synchronised)

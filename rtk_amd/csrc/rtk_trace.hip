@@ -981,10 +981,12 @@ void rtk_scratch_free(LaunchScratch *s)
 
 int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
-	const rtk_dev_filter *filter, rtk_hit_record *d_cand, uint32_t *d_cand_count, uint32_t cand_k)
+	const rtk_dev_filter *filter, rtk_hit_record *d_cand, uint32_t *d_cand_count, uint32_t cand_k, rtk_packet_counters *pk_counted)
 {
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
 	const bool collect = d_cand != nullptr;
+	if (pk_counted && (counted || any_hit || filter || collect)) { rtk_set_error("rtk_dev_trace_rays_packet_counted: closest-hit batches only"); return RTK_AMD_ERR_BAD_ARG; }
+	if (pk_counted) *pk_counted = rtk_packet_counters();
 	if (collect && (!d_cand_count || cand_k == 0 || any_hit || counted)) { rtk_set_error("rtk_dev_trace: bad collect arguments"); return RTK_AMD_ERR_BAD_ARG; }
 	if (!ds || (!d_rays && n) || (!collect && (any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
@@ -1063,10 +1065,16 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	int beam = (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_NO_BEAM)) ? 0 : beam_default;
 	if (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_ONE_TILE_BEAM) && beam == 2) beam = 1;
 	while (beam > 0 && !rtk_packet_hot_available(ds->device, nullptr, beam)) beam--;
+	// the counting form of the kernel that is timed (rtk_packet_count2 = rtk_packet_beam2.S with -DRTK_COUNT): only where that kernel runs
+	if (pk_counted) {
+		if (beam != 2 || !rtk_packet_hot_available(ds->device, nullptr, 3)) { rtk_set_error("rtk_dev_trace_rays_packet_counted: rtk_packet_beam2 is not the kernel of this launch"); return RTK_AMD_ERR_UNSUPPORTED; }
+		beam = 3;
+	}
 	int hot_blocks_per_cu = 0;
 	const bool hot = packet && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
 		ds->bound_abs < 0x1p19f && ds->big_leaf_fraction <= 0.02 && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&
 		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu, beam);
+	if (pk_counted && !hot) { rtk_set_error("rtk_dev_trace_rays_packet_counted: this batch does not run on the assembly packet kernel (image hint, whole 64x64-pixel blocks, small leaves)"); return RTK_AMD_ERR_UNSUPPORTED; }
 	const int occ = blocks_per_cu_of(ds->device, variant);
 	if (blocks_per_cu == 0 || blocks_per_cu > (uint32_t)occ) blocks_per_cu = (uint32_t)occ;
 	// Plain closest-hit / any-hit batches on compressed nodes go to the hand-written per-lane kernels (rtk_lane_hot.S); the rays
@@ -1193,7 +1201,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		// (a small grid: the list is empty for most batches, and a launch that only finds that out should cost next to nothing)
 		p.tile_list = sc->d_leftover;
 		const size_t left_blocks = std::min<size_t>(blocks, (size_t)ds->num_cus * 2u);
-		rtk_packet_launch(p, (unsigned)left_blocks, stream, false);
+		rtk_packet_launch(p, (unsigned)left_blocks, stream, pk_counted != nullptr);      // (counting: the handed-back tiles' steps are counted too)
 	} else if (packet) rtk_packet_launch(p, (unsigned)blocks, stream, counted != nullptr);
 	else if (lane_hot) {
 		if (sc->leftover_capacity < n * 2u) {           // (counted in uint32: the list holds one 8-byte word per left-over ray)
@@ -1235,6 +1243,16 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)left_blocks), dim3(BLOCK_THREADS), 0, stream, lp);
 	} else hipLaunchKernelGGL(trace_variant(variant), dim3((unsigned)blocks), dim3(BLOCK_THREADS), 0, stream, p);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
+	if (pk_counted) {
+		unsigned long long c[16];
+		RTK_HIP_CHECK(hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
+		pk_counted->pairs = c[11]; pk_counted->node_steps = c[12]; pk_counted->triangles_fetched = c[13]; pk_counted->triangle_group_tests = c[14];
+		pk_counted->entry_records = c[15];
+		pk_counted->tiles_handed_back = c[RTK_LEFTOVER_COUNT_WORD];
+		pk_counted->handed_back_node_steps = c[7]; pk_counted->handed_back_triangle_steps = c[8];
+		pk_counted->tiles = n >> 6;
+	}
 	if (counted) {
 		unsigned long long c[16], err = 0;
 		RTK_HIP_CHECK(hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);

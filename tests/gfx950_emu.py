@@ -141,6 +141,7 @@ class Wave:
         self.max_instructions = max_instructions
         self.executed = 0
         self.counts = {}
+        self.watch = {"global_load_dword": 0, "s_load_dwordx8": 0, "s_load_dwordx16": 0}      # executions of whole opcodes (tests count a kernel's loads by them)
 
     # ---------------------------------------------------------------- operand access
     def sget(self, tok):
@@ -279,6 +280,8 @@ class Wave:
                 if self.executed > self.max_instructions:
                     raise EmuError("instruction budget exceeded (a wave that does not finish) at %#x %s" % (addr, op))
                 self.counts[op[:2]] = self.counts.get(op[:2], 0) + 1
+                if op in self.watch:
+                    self.watch[op] += 1
                 if op == "s_endpgm":
                     return
                 nxt = self.step(addr, op, ops, mods)
@@ -522,20 +525,27 @@ class Wave:
             self.vsetf(ops[0], (f(ops[3]).astype(np.float64) / f(ops[2]).astype(np.float64)).astype(np.float32))
         elif op == "v_rcp_f32":
             self.vsetf(ops[0], (1.0 / f(ops[1]).astype(np.float64)).astype(np.float32))
-        elif op == "v_pk_fma_f32":
-            sel = mods.get("op_sel", [0, 0, 0])
-            sel_hi = mods.get("op_sel_hi", [1, 1, 1])
-            neg_lo = mods.get("neg_lo", [0, 0, 0])
-            neg_hi = mods.get("neg_hi", [0, 0, 0])
+        elif op in ("v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32"):
+            nsrc = 3 if op == "v_pk_fma_f32" else 2
+            sel = (mods.get("op_sel", [0, 0, 0]) + [0, 0, 0])[:3]
+            sel_hi = (mods.get("op_sel_hi", [1, 1, 1]) + [1, 1, 1])[:3]
+            neg_lo = (mods.get("neg_lo", [0, 0, 0]) + [0, 0, 0])[:3]
+            neg_hi = (mods.get("neg_hi", [0, 0, 0]) + [0, 0, 0])[:3]
             res = []
             for half, (se, ng) in enumerate(((sel, neg_lo), (sel_hi, neg_hi))):
                 vals = []
-                for i in range(3):
+                for i in range(nsrc):
                     v64 = self.src64(ops[1 + i])
                     word = ((v64 >> np.uint64(32 * se[i])) & np.uint64(0xffffffff)).astype(np.uint32)
-                    x = _f32(word).astype(np.float64)
+                    x = _f32(word)
                     vals.append(-x if ng[i] else x)
-                res.append(_u32((vals[0] * vals[1] + vals[2]).astype(np.float32)))
+                if op == "v_pk_fma_f32":
+                    r = (vals[0].astype(np.float64) * vals[1].astype(np.float64) + vals[2].astype(np.float64)).astype(np.float32)
+                elif op == "v_pk_add_f32":
+                    r = (vals[0] + vals[1]).astype(np.float32)          # float32 arithmetic: one IEEE rounding, as the instruction's
+                else:
+                    r = (vals[0] * vals[1]).astype(np.float32)
+                res.append(_u32(r))
             self.vset(ops[0], res)
         elif op in ("v_add_u32", "v_sub_u32", "v_subrev_u32"):
             a, b = s(ops[1]).astype(np.uint64), s(ops[2]).astype(np.uint64)
@@ -639,12 +649,13 @@ class Wave:
                 for l in lanes:
                     self.mem.store(basea + int(vo[l]) + off, b"".join(struct.pack("<I", int(self.v[first + i][l])) for i in range(n)), op)
         elif op in ("global_atomic_add_x2", "global_atomic_add"):
-            # returning form: dst, voffset, data, saddr
-            dst, voff, data_t, sbase = ops
+            # returning form (sc0): dst, voffset, data, saddr; without a return value: voffset, data, saddr
+            returns = len(ops) == 4
+            dst, voff, data_t, sbase = ops if returns else [None] + list(ops)
             basea = self.sget(sbase)
             vo = self.src(voff)
             wide = op.endswith("x2")
-            first = int(re.match(r"v\[?(\d+)", dst).group(1))
+            first = int(re.match(r"v\[?(\d+)", dst).group(1)) if returns else None
             dfirst = int(re.match(r"v\[?(\d+)", data_t).group(1))
             for l in lanes:
                 a = basea + int(vo[l]) + off
@@ -652,12 +663,14 @@ class Wave:
                     old = struct.unpack("<Q", self.mem.load(a, 8, op))[0]
                     add = int(self.v[dfirst][l]) | (int(self.v[dfirst + 1][l]) << 32)
                     self.mem.store(a, struct.pack("<Q", (old + add) & M64), op)
-                    self.v[first][l] = old & 0xffffffff
-                    self.v[first + 1][l] = old >> 32
+                    if returns:
+                        self.v[first][l] = old & 0xffffffff
+                        self.v[first + 1][l] = old >> 32
                 else:
                     old = struct.unpack("<I", self.mem.load(a, 4, op))[0]
                     self.mem.store(a, struct.pack("<I", (old + int(self.v[dfirst][l])) & 0xffffffff), op)
-                    self.v[first][l] = old
+                    if returns:
+                        self.v[first][l] = old
         else:
             raise EmuError("memory instruction not modelled: %s" % op)
         return None
@@ -701,5 +714,5 @@ def run_kernel(obj_path, kernel, mem, kernarg_bytes, workgroups, lds_bytes, wave
         for w in range(waves_per_wg):
             wave = Wave(code, labels, mem, lds, ka, wg, w, max_instructions)
             wave.run()
-            stats.append(dict(wave.counts, total=wave.executed))
+            stats.append(dict(wave.counts, total=wave.executed, **wave.watch))
     return stats

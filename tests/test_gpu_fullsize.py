@@ -50,6 +50,13 @@ def test_coherent_full_batch(api, oracle, scene):
     assert ds.trace(rays, opts=api.make_opts(image=(4096, 4096), no_packet=True), full=False).tobytes() == rec.tobytes()
     # any-hit over the same interval
     assert (ds.trace_any(rays) == (rec["prim"] != 0xFFFFFFFF)).all()
+    # the counting form of the timed kernel (rtk_packet_count2): the same records, and step counts of the size the CPU simulation of
+    # the two-tile walk predicts (scripts/bvh_lab.cpp -tb 20 -pe 8 -pm 1: 31-34 node steps, ~21 triangle tests, ~14 leaves per pair)
+    rec_c, pk = ds.trace_packet_counted(rays, api.make_opts(image=(4096, 4096)))
+    assert rec_c.tobytes() == rec.tobytes()
+    assert pk["tiles"] == N // 64 and pk["pairs"] * 2 == pk["tiles"] and pk["tiles_handed_back"] == 0
+    assert 25.0 < pk["node_steps"] / pk["pairs"] < 40.0, pk
+    assert 10.0 < pk["triangles_fetched"] / pk["pairs"] < 20.0 and 15.0 < pk["triangle_group_tests"] / pk["pairs"] < 28.0, pk
     # strided sample: identical to the oracle on the exported BVH
     blob = oracle.Blob(ds.export_blob())
     sel = np.arange(0, N, 64)

@@ -21,14 +21,16 @@ from .test_lane_asm_emulated import CSRC, NODE, NONE, TRI, build_bvh4, chain_ora
 OBJ = os.path.join(CSRC, "obj", "rtk_packet_hot.o")
 COUNTER_WORDS = 16 + 16 * 8 + 1
 ENTRIES = np.dtype([("olo", "<f4", (3,)), ("ohi", "<f4", (3,)), ("rlo", "<f4", (3,)), ("rhi", "<f4", (3,)), ("count", "<u4"), ("tmin", "<f4"),
-                    ("pad", "<u4", (2,)), ("e", [("ref", "<u4"), ("tlo", "<f4")], (56,))])
-assert ENTRIES.itemsize == 512
+                    ("pad", "<u4", (2,)), ("e", [("ref", "<u4"), ("tlo", "<f4")], (56,)), ("planes", "<f4", (24, 16))])
+assert ENTRIES.itemsize == 2048
 W, H = 128, 64            # two 64x64-pixel blocks = 128 tiles
 
 
 # the two kernels assembled from rtk_packet_hot.S: per-lane slab tests (20 KB of LDS for the stacks) and, with -DRTK_BEAM, the
 # interval test of the tile's own beam (one child plane per lane; no LDS); and rtk_packet_beam2.S: two adjacent tiles per wave
-KERNELS = {"rtk_packet_hot": ("rtk_packet_hot.o", 20480), "rtk_packet_beam": ("rtk_packet_beam.o", 0), "rtk_packet_beam2": ("rtk_packet_beam2.o", 0)}
+# ... and rtk_packet_count2 = rtk_packet_beam2.S with -DRTK_COUNT (three step counters per pair of tiles): every test here runs on it too
+KERNELS = {"rtk_packet_hot": ("rtk_packet_hot.o", 20480), "rtk_packet_beam": ("rtk_packet_beam.o", 0), "rtk_packet_beam2": ("rtk_packet_beam2.o", 0),
+           "rtk_packet_count2": ("rtk_packet_count2.o", 0)}
 
 
 @pytest.fixture(scope="module", params=sorted(KERNELS))
@@ -92,12 +94,15 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
                     n = max(n, f(min(ns) - m[a]))
                     far = min(far, f(max(fs) + m[a]))
                 return n <= far, n
-            cur, listed, over = [(0, f(e["tmin"]))], [], False
+            # (every frontier / listed node with the box it has in its parent: the record lists the entries' boxes by plane)
+            e["planes"][:] = np.where((np.arange(24) & 4) != 0, f(-1.0), f(1.0))[:, None]
+            root_box = ([f(-bound)] * 3, [f(bound)] * 3)
+            cur, listed, over = [(0, f(e["tmin"]), root_box)], [], False
             for level in range(14):
                 if not cur or (level > 0 and len(listed) + len(cur) >= target):
                     break
                 nxt = []
-                for ref, t_self in cur:
+                for ref, t_self, box_self in cur:
                     nd = nodes[ref]
                     reached = []
                     for k in range(4):
@@ -106,9 +111,9 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
                             continue
                         ok_k, tlo = child(nd, k)
                         if ok_k:
-                            reached.append((c, tlo))
-                    if any(c & 0x80000000 for c, _ in reached):
-                        listed.append((ref, t_self))         # a node with a leaf child the beam reaches is listed itself
+                            reached.append((c, tlo, ([f(nd[ax][0][k]) for ax in ("bx", "by", "bz")], [f(nd[ax][1][k]) for ax in ("bx", "by", "bz")])))
+                    if any(c & 0x80000000 for c, _, _ in reached):
+                        listed.append((ref, t_self, box_self))         # a node with a leaf child the beam reaches is listed itself
                     else:
                         nxt += reached
                 over = over or len(listed) > 56 or len(nxt) > 128
@@ -122,6 +127,10 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
             e["count"] = len(listed)
             for q, i in enumerate(order):
                 e["e"][q] = (listed[i][0], listed[i][1])
+                lo, hi = listed[i][2]
+                for a in range(3):
+                    e["planes"][a * 8 + (q & 3)][q >> 2] = lo[a]
+                    e["planes"][a * 8 + 4 + (q & 3)][q >> 2] = hi[a]
     return out
 
 
@@ -144,6 +153,7 @@ def run_packet_kernel(obj, nodes, tr, rays, w, h, entries=None, bound=None, work
     res = mem.get(a_o).view(HIT_RECORD_DTYPE).copy()
     counter = mem.get(a_c).view(np.uint64)
     left = mem.get(a_l).view(np.uint32)[:int(counter[10])].copy()
+    run_packet_kernel.last_counters = counter[:16].copy()
     return res, left, stats
 
 
@@ -255,7 +265,7 @@ def test_a_stack_deeper_than_the_registers_hands_the_tile_back(packet_obj, oracl
         assert 0.01 < g_mask.mean() < 0.3
         res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, workgroups=1, bound=6.0)
         done = check(res, left, g_hits, g_mask, rays, W, H)
-        answers = beam_answers if packet_obj in ("rtk_packet_beam", "rtk_packet_beam2") else levels == 6
+        answers = beam_answers if packet_obj in ("rtk_packet_beam", "rtk_packet_beam2", "rtk_packet_count2") else levels == 6
         # (the tiles that reach the box: all answered, or all handed back)
         assert done.all() if answers else (len(left) > 0 and not g_mask[done].any())
 
@@ -273,4 +283,46 @@ def test_one_tile_of_a_pair_outside_the_beam(packet_obj, oracle, scene):
         ent = beam_entries(nodes, rays, W, H, bound=2.0, target=12)
         assert (ent["count"] > 1).all()
         res, left, _ = run_packet_kernel(packet_obj, nodes, tr, rays, W, H, entries=ent, workgroups=1)
+        assert len(left) == 0 and check(res, left, g_hits, g_mask, rays, W, H).all()
+
+
+def test_the_counting_form_counts_what_the_kernel_loads(oracle, scene):
+    """rtk_packet_count2 (rtk_packet_beam2.S assembled with -DRTK_COUNT) is the kernel that is timed plus three scalar counters per
+    pair of tiles. Its records are rtk_packet_beam2's; its counters equal what the emulator saw the kernel DO: one node step per
+    128-byte node line asked for (global_load_dword: the kernel's only use of that opcode), one triangle fetched per 48-byte record
+    asked for (s_load_dwordx8: triangles, and once per wave the kernel argument), pairs = tiles / 2; tests lie between the triangles
+    fetched (every one is tested for at least one group) and twice that."""
+    subprocess.check_call(["make", "-s", "-C", CSRC, os.path.join(os.path.abspath(CSRC), "obj", "rtk_packet_hot.hsaco")])
+    tv, tr, nodes = scene
+    for rays, with_lists in ((camera(0.02, 0.05, 0.55), False), (camera(0.20, 0.22, 0.05), True), (camera(-0.25, -0.12, 0.5), True)):
+        ent = beam_entries(nodes, rays, W, H, bound=2.0, target=8) if with_lists else None
+        want, left_b, _ = run_packet_kernel("rtk_packet_beam2", nodes, tr, rays, W, H, entries=ent, workgroups=1)
+        got, left_c, stats = run_packet_kernel("rtk_packet_count2", nodes, tr, rays, W, H, entries=ent, workgroups=1)
+        c = run_packet_kernel.last_counters
+        assert got.tobytes() == want.tobytes() and sorted(left_b.tolist()) == sorted(left_c.tolist())
+        pairs, node_steps, fetched, tests = (int(c[k]) for k in (11, 12, 13, 14))
+        assert pairs == W * H // 128
+        lists = int(c[15])                    # pairs that took their block's entry record (its references come by one global_load_dword)
+        assert (lists > 0) == (with_lists and bool((ent["count"] > 0).any())) and lists <= pairs
+        assert node_steps == sum(s["global_load_dword"] for s in stats) - lists > 0
+        assert fetched == sum(s["s_load_dwordx8"] for s in stats) - len(stats) > 0
+        assert fetched <= tests <= 2 * fetched
+        assert int(c[10]) == len(left_c)
+
+
+@pytest.mark.parametrize("shift", [1, 2])
+def test_the_other_two_dominant_axes(oracle, shift):
+    """The triangle code exists three times, once per dominant axis of the packet; the cameras above look down z (the packed form,
+    TRI_BODY_PK). Here scene and rays are rotated through the axes (x -> y -> z -> x, once and twice), so the tiles' dominant axis is
+    x or y and the single-instruction form with its own permutation of vertex and origin components runs: bit for bit the oracle."""
+    subprocess.check_call(["make", "-s", "-C", CSRC, os.path.join(os.path.abspath(CSRC), "obj", "rtk_packet_hot.hsaco")])
+    tv = np.roll(synth.triangle_soup(500, 0.15, seed=11).reshape(-1, 3, 3), shift, axis=2).copy()
+    qn, tr, nodes = build_bvh4(tv, want_exact=True)
+    rays = camera(0.02, 0.05, 0.55)
+    rays["origin"] = np.roll(rays["origin"], shift, axis=1)
+    rays["direction"] = np.roll(rays["direction"], shift, axis=1)
+    g_hits, g_mask = chain_oracle(oracle, tv, rays)
+    assert 0.2 < g_mask.mean() < 0.98
+    for obj in ("rtk_packet_beam2", "rtk_packet_beam"):
+        res, left, _ = run_packet_kernel(obj, nodes, tr, rays, W, H, workgroups=1)
         assert len(left) == 0 and check(res, left, g_hits, g_mask, rays, W, H).all()
