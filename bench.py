@@ -530,10 +530,9 @@ def main():
     if packet_kernel and pk_ctr:
         fetched_nodes = pk_ctr["node_steps"] + pk_ctr["handed_back_node_steps"]
         fetched_tris = pk_ctr["triangles_fetched"] + pk_ctr["handed_back_triangle_steps"]
-        ENTRY_RECORD_BYTES = 64 + 256 + 1536      # what a pair reads of its block's PkBlockEntries: header, 64 reference words, 24 planes x 16 virtual nodes
-        alg_bytes = n * (RAY_BYTES + out_bytes) + fetched_nodes * NODE_BYTES + fetched_tris * TRI_BYTES + pk_ctr["entry_records"] * ENTRY_RECORD_BYTES
+        alg_bytes = n * (RAY_BYTES + out_bytes) + fetched_nodes * NODE_BYTES + fetched_tris * TRI_BYTES
         unit = ("PAIR of adjacent 8x8-pixel tiles (128 rays, one wave): 32 B per ray in, 16 B per ray out, each node (128 B) priced once per node "
-                "step of the pair, each triangle record (48 B) once per triangle of a leaf the pair enters, 1856 B of its block's entry record; steps counted by rtk_packet_count2, "
+                "step of the pair and each triangle record (48 B) once per triangle of a leaf the pair enters; steps counted by rtk_packet_count2, "
                 "the kernel that is timed assembled with -DRTK_COUNT (rtk_dev_trace_rays_packet_counted), plus the C++ packet kernel's own "
                 "counting build on the %d tiles handed back" % pk_ctr["tiles_handed_back"])
     elif packet_kernel:
@@ -709,7 +708,7 @@ def main():
                      "timed_kernel_steps": ({"per_pair_of_tiles": {"node_steps": round(pk_ctr["node_steps"] / max(1, pk_ctr["pairs"]), 2),
                                                                   "triangles_fetched": round(pk_ctr["triangles_fetched"] / max(1, pk_ctr["pairs"]), 2),
                                                                   "triangle_group_tests": round(pk_ctr["triangle_group_tests"] / max(1, pk_ctr["pairs"]), 2)},
-                                             "pairs": pk_ctr["pairs"], "entry_records_taken": pk_ctr["entry_records"], "tiles_handed_back": pk_ctr["tiles_handed_back"],
+                                             "pairs": pk_ctr["pairs"], "tiles_handed_back": pk_ctr["tiles_handed_back"],
                                              "handed_back_node_steps": pk_ctr["handed_back_node_steps"], "handed_back_triangle_steps": pk_ctr["handed_back_triangle_steps"],
                                              "counted_by": "rtk_packet_count2 (rtk_packet_beam2.S -DRTK_COUNT)"} if pk_ctr else None),
                      "per_ray_model": {"bytes_per_ray": round(per_ray_bytes / n, 1), "gb_s": round(per_ray_bytes / (k_ms * 1e-3) / 1e9, 1),

@@ -222,7 +222,6 @@ typedef struct rtk_packet_counters {
 	uint64_t tiles_handed_back;          /* tiles traced again from the start by the C++ packet kernel */
 	uint64_t handed_back_node_steps;     /* ... its wave-level node steps (one tile per wave) */
 	uint64_t handed_back_triangle_steps; /* ... and triangle steps */
-	uint64_t entry_records;              /* pairs that took their block's entry record (64 B header + 256 B of references + 1536 B of entry boxes) */
 } rtk_packet_counters;
 int rtk_dev_trace_rays_packet_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, rtk_packet_counters *out);

@@ -74,7 +74,7 @@ class PacketCounters(C.Structure):
     """rtk_packet_counters: step counts of rtk_packet_count2 (the counting form of rtk_packet_beam2)."""
     _fields_ = [("tiles", C.c_uint64), ("pairs", C.c_uint64), ("node_steps", C.c_uint64), ("triangles_fetched", C.c_uint64),
                 ("triangle_group_tests", C.c_uint64), ("tiles_handed_back", C.c_uint64),
-                ("handed_back_node_steps", C.c_uint64), ("handed_back_triangle_steps", C.c_uint64), ("entry_records", C.c_uint64)]
+                ("handed_back_node_steps", C.c_uint64), ("handed_back_triangle_steps", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

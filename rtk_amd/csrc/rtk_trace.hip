@@ -1248,7 +1248,6 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		RTK_HIP_CHECK(hipMemcpyAsync(c, sc->d_counter, sizeof(c), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 		RTK_HIP_CHECK(hipStreamSynchronize(stream), RTK_AMD_ERR_HIP);
 		pk_counted->pairs = c[11]; pk_counted->node_steps = c[12]; pk_counted->triangles_fetched = c[13]; pk_counted->triangle_group_tests = c[14];
-		pk_counted->entry_records = c[15];
 		pk_counted->tiles_handed_back = c[RTK_LEFTOVER_COUNT_WORD];
 		pk_counted->handed_back_node_steps = c[7]; pk_counted->handed_back_triangle_steps = c[8];
 		pk_counted->tiles = n >> 6;

@@ -678,9 +678,6 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 	__shared__ float s_t[2][PK_FRONTIER];
 	__shared__ uint32_t s_out_ref[PK_MAX_ENTRIES];
 	__shared__ float s_out_t[PK_MAX_ENTRIES];
-	// the box every frontier / listed node has in its parent (minima x y z, maxima x y z): the entries' boxes go into the record
-	__shared__ float s_box[2][PK_FRONTIER][6];
-	__shared__ float s_out_box[PK_MAX_ENTRIES][6];
 	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
 	const uint32_t bx = blk % blocks_per_row, by = blk / blocks_per_row;
 	PkBeam b;
@@ -731,9 +728,6 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 	uint32_t n_cur = 1u, n_out = 0u, cur = 0u;
 	bool over = false;
 	if (lane == 0) { s_ref[0][0] = 0u; s_t[0][0] = b.tmin; }
-	if (lane < 6u) s_box[0][0][lane] = lane < 3u ? -bound_abs : bound_abs;        // the root has no box of its own: the scene's bound
-	// the record's box table starts out empty (+1 / -1: rtk.c:1612-1620): 24 planes x 16 virtual nodes, six floats per lane
-	for (uint32_t i = lane; i < 24u * PK_VIRTUAL_NODES; i += 64u) (&e->planes[0][0])[i] = ((i / PK_VIRTUAL_NODES) & 4u) ? -1.0f : 1.0f;
 	__syncthreads();
 	// (a block that looks past the scene's edge finds few nodes per level and would walk to the leaves: the deepest walk is the
 	// kernel's duration -- 30 us at 14 levels, 26 at 8 --, so the walk is capped)
@@ -760,7 +754,7 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 			const unsigned long long m_out = __builtin_amdgcn_ballot_w64(list_self);
 			if (list_self) {
 				const uint32_t at = n_out + (uint32_t)__popcll(m_out & below);
-				if (at < PK_MAX_ENTRIES) { s_out_ref[at] = ref; s_out_t[at] = t_self; for (int q = 0; q < 6; q++) s_out_box[at][q] = s_box[cur][base + lane][q]; }
+				if (at < PK_MAX_ENTRIES) { s_out_ref[at] = ref; s_out_t[at] = t_self; }
 			}
 			n_out += (uint32_t)__popcll(m_out);
 #pragma unroll
@@ -769,11 +763,7 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 				const unsigned long long m_next = __builtin_amdgcn_ballot_w64(push);
 				if (push) {
 					const uint32_t at = n_next + (uint32_t)__popcll(m_next & below);
-					if (at < PK_FRONTIER) {
-						s_ref[cur ^ 1u][at] = nd.child[k]; s_t[cur ^ 1u][at] = tlo[k];
-						float *bb = s_box[cur ^ 1u][at];
-						bb[0] = nd.bx[0][k]; bb[1] = nd.by[0][k]; bb[2] = nd.bz[0][k]; bb[3] = nd.bx[1][k]; bb[4] = nd.by[1][k]; bb[5] = nd.bz[1][k];
-					}
+					if (at < PK_FRONTIER) { s_ref[cur ^ 1u][at] = nd.child[k]; s_t[cur ^ 1u][at] = tlo[k]; }
 				}
 				n_next += (uint32_t)__popcll(m_next);
 			}
@@ -786,10 +776,7 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 	}
 	// the nodes that were not opened are entries too
 	if (!over) {
-		for (uint32_t i = lane; i < n_cur; i += 64u) if (n_out + i < PK_MAX_ENTRIES) {
-			s_out_ref[n_out + i] = s_ref[cur][i]; s_out_t[n_out + i] = s_t[cur][i];
-			for (int q = 0; q < 6; q++) s_out_box[n_out + i][q] = s_box[cur][i][q];
-		}
+		for (uint32_t i = lane; i < n_cur; i += 64u) if (n_out + i < PK_MAX_ENTRIES) { s_out_ref[n_out + i] = s_ref[cur][i]; s_out_t[n_out + i] = s_t[cur][i]; }
 		n_out += n_cur;
 		over = n_out > PK_MAX_ENTRIES;
 	}
@@ -802,9 +789,6 @@ __global__ void __launch_bounds__(64) rtk_packet_entries_kernel(const DevNode *n
 		for (uint32_t j = 0; j < n_out; j++) { const float tj = s_out_t[j]; rank += (tj < t || (tj == t && j < lane)) ? 1u : 0u; }
 		e->e[rank].ref = s_out_ref[lane];
 		e->e[rank].tlo = t;
-		// its box: slot rank & 3 of virtual node rank >> 2; plane p = axis * 8 + (0 minima | 4 maxima) + slot
-		const uint32_t v = rank >> 2, slot = rank & 3u;
-		for (int a = 0; a < 3; a++) { e->planes[a * 8 + slot][v] = s_out_box[lane][a]; e->planes[a * 8 + 4 + slot][v] = s_out_box[lane][3 + a]; }
 	}
 	if (lane == 0) e->count = n_out;
 }

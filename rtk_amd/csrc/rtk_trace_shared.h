@@ -61,24 +61,15 @@ struct TraceParams {
 // tile of the block a triangle test whether or not any of its rays enters the leaf's box (measured: +25 % triangle tests).
 // (Listed in the order a traversal from the root reaches them, with the smallest bound of the rest for the early exit, tiles
 // visited more nodes and were slower than from the root: profiles/r04_packet_entries.log.)
-// Round 5: the record also carries the BOXES of the entries, as sixteen "virtual nodes" of four consecutive entries each, laid out by
-// plane: planes[p][v], p = the plane's float offset inside a DevNode (axis * 8 + (0 minima | 4 maxima) + slot), v = virtual node, so a
-// lane of the plane-per-lane test (rtk_packet_beam2.S) reads its plane of ALL sixteen virtual nodes with four 16-byte loads. A pair of
-// tiles tests every entry's box against its own two beams at once, before anything of the tree is fetched, and pushes the entries
-// some ray may reach: one round trip instead of one per entry plus one per entry node that turns out to be missed (a third of a
-// pair's dependent fetches were these). Unused slots carry the empty box (+1 / -1) and the reference "none".
 #define PK_MAX_ENTRIES 56
-#define PK_VIRTUAL_NODES 16
 struct PkBlockEntries {
 	float olo[3], ohi[3];          //  0  the beam: origins ...
 	float rlo[3], rhi[3];          // 24  ... and reciprocal directions of the block's rays
 	uint32_t count;                // 48  entries; 0 = none (rays of mixed signs, not tame, too many entries): tiles start at the root
 	uint32_t pad[3];
 	struct { uint32_t ref; float tlo; } e[PK_MAX_ENTRIES];   // 64  node reference, lower bound of the entry distance (ascending)
-	float planes[24][PK_VIRTUAL_NODES];                       // 512 entry boxes by plane (see above)
 };
-static_assert(sizeof(PkBlockEntries) == 2048 && offsetof(PkBlockEntries, count) == 48 && offsetof(PkBlockEntries, e) == 64 && offsetof(PkBlockEntries, planes) == 512,
-	"rtk_packet_hot.S / rtk_packet_beam2.S read this layout");
+static_assert(sizeof(PkBlockEntries) == 512 && offsetof(PkBlockEntries, count) == 48 && offsetof(PkBlockEntries, e) == 64, "rtk_packet_hot.S reads this layout");
 
 // Kernel argument of rtk_packet_hot (rtk_packet_hot.S reads these offsets)
 struct PkHotParams {

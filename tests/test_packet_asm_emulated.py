@@ -21,8 +21,8 @@ from .test_lane_asm_emulated import CSRC, NODE, NONE, TRI, build_bvh4, chain_ora
 OBJ = os.path.join(CSRC, "obj", "rtk_packet_hot.o")
 COUNTER_WORDS = 16 + 16 * 8 + 1
 ENTRIES = np.dtype([("olo", "<f4", (3,)), ("ohi", "<f4", (3,)), ("rlo", "<f4", (3,)), ("rhi", "<f4", (3,)), ("count", "<u4"), ("tmin", "<f4"),
-                    ("pad", "<u4", (2,)), ("e", [("ref", "<u4"), ("tlo", "<f4")], (56,)), ("planes", "<f4", (24, 16))])
-assert ENTRIES.itemsize == 2048
+                    ("pad", "<u4", (2,)), ("e", [("ref", "<u4"), ("tlo", "<f4")], (56,))])
+assert ENTRIES.itemsize == 512
 W, H = 128, 64            # two 64x64-pixel blocks = 128 tiles
 
 
@@ -94,15 +94,12 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
                     n = max(n, f(min(ns) - m[a]))
                     far = min(far, f(max(fs) + m[a]))
                 return n <= far, n
-            # (every frontier / listed node with the box it has in its parent: the record lists the entries' boxes by plane)
-            e["planes"][:] = np.where((np.arange(24) & 4) != 0, f(-1.0), f(1.0))[:, None]
-            root_box = ([f(-bound)] * 3, [f(bound)] * 3)
-            cur, listed, over = [(0, f(e["tmin"]), root_box)], [], False
+            cur, listed, over = [(0, f(e["tmin"]))], [], False
             for level in range(14):
                 if not cur or (level > 0 and len(listed) + len(cur) >= target):
                     break
                 nxt = []
-                for ref, t_self, box_self in cur:
+                for ref, t_self in cur:
                     nd = nodes[ref]
                     reached = []
                     for k in range(4):
@@ -111,9 +108,9 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
                             continue
                         ok_k, tlo = child(nd, k)
                         if ok_k:
-                            reached.append((c, tlo, ([f(nd[ax][0][k]) for ax in ("bx", "by", "bz")], [f(nd[ax][1][k]) for ax in ("bx", "by", "bz")])))
-                    if any(c & 0x80000000 for c, _, _ in reached):
-                        listed.append((ref, t_self, box_self))         # a node with a leaf child the beam reaches is listed itself
+                            reached.append((c, tlo))
+                    if any(c & 0x80000000 for c, _ in reached):
+                        listed.append((ref, t_self))         # a node with a leaf child the beam reaches is listed itself
                     else:
                         nxt += reached
                 over = over or len(listed) > 56 or len(nxt) > 128
@@ -127,10 +124,6 @@ def beam_entries(nodes, rays, w, h, bound, target=20):
             e["count"] = len(listed)
             for q, i in enumerate(order):
                 e["e"][q] = (listed[i][0], listed[i][1])
-                lo, hi = listed[i][2]
-                for a in range(3):
-                    e["planes"][a * 8 + (q & 3)][q >> 2] = lo[a]
-                    e["planes"][a * 8 + 4 + (q & 3)][q >> 2] = hi[a]
     return out
 
 
@@ -302,9 +295,7 @@ def test_the_counting_form_counts_what_the_kernel_loads(oracle, scene):
         assert got.tobytes() == want.tobytes() and sorted(left_b.tolist()) == sorted(left_c.tolist())
         pairs, node_steps, fetched, tests = (int(c[k]) for k in (11, 12, 13, 14))
         assert pairs == W * H // 128
-        lists = int(c[15])                    # pairs that took their block's entry record (its references come by one global_load_dword)
-        assert (lists > 0) == (with_lists and bool((ent["count"] > 0).any())) and lists <= pairs
-        assert node_steps == sum(s["global_load_dword"] for s in stats) - lists > 0
+        assert node_steps == sum(s["global_load_dword"] for s in stats) > 0
         assert fetched == sum(s["s_load_dwordx8"] for s in stats) - len(stats) > 0
         assert fetched <= tests <= 2 * fetched
         assert int(c[10]) == len(left_c)
