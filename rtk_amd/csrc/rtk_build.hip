@@ -85,9 +85,13 @@ __device__ __forceinline__ float ord2f(uint32_t u)
 // The bounds of the triangle centroids (x2, see k_bounds) are taken in the same pass: one 1024-thread workgroup per CU at
 // most, so the six result words see a few hundred atomics, not tens of thousands.
 #define INGEST_BLOCK 1024
-template <int IDX, bool F64>
+// DIRECT (implicit indices, float positions): nothing is staged -- k_emit_tris gathers the three vertices of a sorted triangle
+// straight from the caller's (or the uploaded) position buffer. Every form writes the doubled centroid (12 B: all k_morton
+// needs; it used to read the whole 48-byte staged record for it) and, if the scene keeps them (vidx_in: some mesh is indexed),
+// the original vertex indices in input order.
+template <int IDX, bool F64, bool DIRECT>
 __global__ void __launch_bounds__(INGEST_BLOCK) k_ingest(const char *pos, unsigned long long pos_stride, const char *idx,
-	unsigned long long idx_stride, uint32_t ntris, uint32_t base, InTri *in_tris, uint32_t *bounds)
+	unsigned long long idx_stride, uint32_t ntris, uint32_t base, InTri *in_tris, float *cent, uint32_t *vidx_in, uint32_t *bounds)
 {
 	__shared__ float s_mn[3][INGEST_BLOCK / 64], s_mx[3][INGEST_BLOCK / 64];
 	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -120,14 +124,18 @@ __global__ void __launch_bounds__(INGEST_BLOCK) k_ingest(const char *pos, unsign
 			rec.p[3 * c + 2] = z;
 			rec.vi[c] = vi[c];
 		}
-		float4 *out = reinterpret_cast<float4 *>(in_tris + g);
-		const float4 *src = reinterpret_cast<const float4 *>(&rec);
-		out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
+		if (!DIRECT) {
+			float4 *out = reinterpret_cast<float4 *>(in_tris + g);
+			const float4 *src = reinterpret_cast<const float4 *>(&rec);
+			out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
+		}
+		if (vidx_in) { vidx_in[3 * g + 0] = vi[0]; vidx_in[3 * g + 1] = vi[1]; vidx_in[3 * g + 2] = vi[2]; }
 #pragma unroll
 		for (int a = 0; a < 3; a++) {
 			const float lo = fminf(fminf(rec.p[a], rec.p[3 + a]), rec.p[6 + a]);
 			const float hi = fmaxf(fmaxf(rec.p[a], rec.p[3 + a]), rec.p[6 + a]);
 			const float c2 = lo + hi;
+			cent[3 * g + a] = c2;
 			mn[a] = fminf(mn[a], c2);
 			mx[a] = fmaxf(mx[a], c2);
 		}
@@ -151,11 +159,12 @@ __global__ void __launch_bounds__(INGEST_BLOCK) k_ingest(const char *pos, unsign
 }
 
 template <int IDX>
-void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
-	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris, uint32_t *bounds, hipStream_t stream)
+void launch_ingest(bool f64, bool direct, unsigned blocks, const char *pos, unsigned long long pstride, const char *idx,
+	unsigned long long istride, uint32_t nt, uint32_t base, InTri *in_tris, float *cent, uint32_t *vidx_in, uint32_t *bounds, hipStream_t stream)
 {
-	if (f64) hipLaunchKernelGGL((k_ingest<IDX, true>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, bounds);
-	else hipLaunchKernelGGL((k_ingest<IDX, false>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, bounds);
+	if (direct) hipLaunchKernelGGL((k_ingest<0, false, true>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, cent, vidx_in, bounds);
+	else if (f64) hipLaunchKernelGGL((k_ingest<IDX, true, false>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, cent, vidx_in, bounds);
+	else hipLaunchKernelGGL((k_ingest<IDX, false, false>), dim3(blocks), dim3(INGEST_BLOCK), 0, stream, pos, pstride, idx, istride, nt, base, in_tris, cent, vidx_in, bounds);
 }
 
 // ---------------------------------------------------------------------------------- 2 bounds
@@ -163,17 +172,21 @@ void launch_ingest(bool f64, unsigned blocks, const char *pos, unsigned long lon
 // bounds[0..2] = min of centroid*2 (ordered uint), bounds[3..5] = max. One 1024-thread workgroup per CU: the six result
 // words take ~300 atomics/us between them, and 2048 workgroups x 6 atomics cost four times the data pass at 1M triangles.
 #define BOUNDS_BLOCK 1024
-__global__ void __launch_bounds__(BOUNDS_BLOCK) k_bounds(const InTri *in_tris, uint32_t n, uint32_t *bounds)
+// (the staged records [first, first + n) of one host-decoded mesh: their doubled centroids, vertex indices and bounds)
+__global__ void __launch_bounds__(BOUNDS_BLOCK) k_bounds(const InTri *in_tris, uint32_t first, uint32_t n, uint32_t *bounds, float *cent, uint32_t *vidx_in)
 {
 	__shared__ float s_mn[3][BOUNDS_BLOCK / 64], s_mx[3][BOUNDS_BLOCK / 64];
 	float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+	for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+		const size_t i = (size_t)first + k;
 		const float *p = in_tris[i].p;
 #pragma unroll
 		for (int a = 0; a < 3; a++) {
 			const float lo = fminf(fminf(p[a], p[3 + a]), p[6 + a]);
 			const float hi = fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
 			const float c2 = lo + hi;
+			cent[3 * i + a] = c2;
+			if (vidx_in) vidx_in[3 * i + a] = in_tris[i].vi[a];
 			mn[a] = fminf(mn[a], c2);
 			mx[a] = fmaxf(mx[a], c2);
 		}
@@ -209,16 +222,15 @@ __device__ __forceinline__ unsigned long long spread21(uint32_t v)
 	return x;
 }
 
-__global__ void k_morton(const InTri *in_tris, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals, uint32_t drop_bits)
+__global__ void k_morton(const float *cent, uint32_t n, const uint32_t *bounds, unsigned long long *keys, uint32_t *vals, uint32_t drop_bits)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const float *p = in_tris[i].p;
 	uint32_t q[3];
 #pragma unroll
 	for (int a = 0; a < 3; a++) {
 		const float lo = ord2f(bounds[a]), hi = ord2f(bounds[3 + a]);
-		const float c2 = fminf(fminf(p[a], p[3 + a]), p[6 + a]) + fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
+		const float c2 = cent[3 * (size_t)i + a];            // min + max of the triangle's three coordinates, as the ingest pass left it
 		const float ext = hi - lo;
 		float t = ext > 0.0f ? (c2 - lo) / ext : 0.0f;
 		t = fminf(fmaxf(t, 0.0f), 1.0f);
@@ -431,37 +443,63 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 
 // ---------------------------------------------------------------------------------- 5 emit
 
-__global__ void k_emit_tris(const InTri *in_tris, const uint32_t *vals, const unsigned long long *words, uint32_t n,
-	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris, uint32_t *vertex_index,
-	uint32_t *prim_slot, uint32_t *slot_mesh, uint32_t *slot_tri)
+// where the positions of a mesh's triangles are read from: its own buffer (implicit indices, float positions: vertex 3 i + c of
+// triangle i at pos + (3 i + c) * stride), or the staged records (pos == NULL)
+struct MeshSrc { const char *pos; unsigned long long stride; };
+
+__global__ void k_emit_tris(const InTri *in_tris, const MeshSrc *src, const uint32_t *vals, const unsigned long long *words, uint32_t n,
+	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris)
 {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n) return;
 	const uint32_t g = vals ? vals[s] : (uint32_t)(words[s] & 0xffffffull);     // packed sort words carry the index in their low 24 bits
-	const float4 *src = reinterpret_cast<const float4 *>(in_tris + g);
-	const float4 a = src[0], b = src[1], c = src[2];      // p0 p1 p2 p3 | p4 p5 p6 p7 | p8 vi0 vi1 vi2
 	// mesh of global primitive g: last m with mesh_base[m] <= g
 	uint32_t lo = 0, hi = num_meshes;
 	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
+	const MeshSrc ms = src[lo];
 	DevTri t;
-	t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.prim = g;
+	if (ms.pos) {
+		const size_t first = 3u * (size_t)(g - (uint32_t)mesh_base[lo]);
+		const float *p0 = reinterpret_cast<const float *>(ms.pos + first * ms.stride);
+		const float *p1 = reinterpret_cast<const float *>(ms.pos + (first + 1u) * ms.stride);
+		const float *p2 = reinterpret_cast<const float *>(ms.pos + (first + 2u) * ms.stride);
+		t.v0[0] = p0[0]; t.v0[1] = p0[1]; t.v0[2] = p0[2];
+		t.v1[0] = p1[0]; t.v1[1] = p1[1]; t.v1[2] = p1[2];
+		t.v2[0] = p2[0]; t.v2[1] = p2[1]; t.v2[2] = p2[2];
+	} else {
+		const float4 *rec = reinterpret_cast<const float4 *>(in_tris + g);
+		const float4 a = rec[0], b = rec[1], c = rec[2];      // p0 p1 p2 p3 | p4 p5 p6 p7 | p8 vi0 vi1 vi2
+		t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z;
+		t.v1[0] = a.w; t.v1[1] = b.x; t.v1[2] = b.y;
+		t.v2[0] = b.z; t.v2[1] = b.w; t.v2[2] = c.x;
+	}
 	// every record starts out as a leaf of its own (count 1, last of its leaf); the collapse rewrites only the
 	// members of multi-triangle leaves
-	t.v1[0] = a.w; t.v1[1] = b.x; t.v1[2] = b.y; t.flags = (lo << 8) | RTK_TRI_LAST;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
-	t.v2[0] = b.z; t.v2[1] = b.w; t.v2[2] = c.x; t.spare = 1u;
+	t.prim = g;
+	t.flags = (lo << 8) | RTK_TRI_LAST;   // mesh index above the flag bits (RTK_TRI_MESH_SHIFT)
+	t.spare = 1u;
 #if RTK_TRI_STRIDE == 64
 	t.pad[0] = t.pad[1] = t.pad[2] = t.pad[3] = 0u;
 #endif
 	tris[s] = t;
-	vertex_index[3 * (size_t)s + 0] = __float_as_uint(c.y);
-	vertex_index[3 * (size_t)s + 1] = __float_as_uint(c.z);
-	vertex_index[3 * (size_t)s + 2] = __float_as_uint(c.w);
-	// (these three tables are read by the expansion of hit records and the validator only; written by a kernel of their own on the
-	// build's side stream, beside the refit, they cost more than here: 2.82 against 2.72 ms at 10M triangles -- a second pass over
-	// the triangle records)
+	// (the side arrays -- original vertex indices, primitive -> slot, slot -> mesh / triangle -- were written here, 52 bytes per
+	// triangle with one scattered word: rtk_scene_side_arrays makes them when something asks for a full rtk_hit, a validation or
+	// an export, not in every build)
+}
+
+// The view's side arrays from the finished triangle records (DevTri carries the primitive id and the mesh index), once per scene.
+__global__ void k_side_arrays(const DevTri *tris, uint32_t n, const unsigned long long *mesh_base, const uint32_t *vidx_in,
+	uint32_t *vertex_index, uint32_t *prim_slot, uint32_t *slot_mesh, uint32_t *slot_tri)
+{
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tris) + (size_t)s * RTK_TRI_STRIDE);
+	const uint32_t g = w[3], mesh = w[7] >> 8;
+	const uint32_t tri = g - (uint32_t)mesh_base[mesh];
+	for (uint32_t c = 0; c < 3u; c++) vertex_index[3 * (size_t)s + c] = vidx_in ? vidx_in[3 * (size_t)g + c] : 3u * tri + c;
 	prim_slot[g] = s;
-	slot_mesh[s] = lo;
-	slot_tri[s] = g - (uint32_t)mesh_base[lo];
+	slot_mesh[s] = mesh;
+	slot_tri[s] = tri;
 }
 
 // ---------------------------------------------------------------------------------- 6 tree topology
@@ -1584,6 +1622,8 @@ struct MeshPlan {
 	size_t pbytes = 0, ibytes = 0;  // bytes to upload (0: already device memory / nothing)
 	const char *pos_src = nullptr, *idx_src = nullptr;
 	bool pos_on_device = false, idx_on_device = false;
+	bool direct = false;            // implicit indices, float positions: nothing staged, k_emit_tris gathers from the position buffer itself
+	const char *dev_pos = nullptr;  // where the ingest kernel read the positions (the caller's device buffer or the uploaded copy)
 };
 
 int cached_cu_count(int device)
@@ -1715,7 +1755,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	const size_t sort_words = rtk_sort_scratch_words(n);
 	const size_t collapse_blocks = ((size_t)n + COLLAPSE_BLOCK - 1) / COLLAPSE_BLOCK;
 	size_t need = upload_bytes + 64 * 256;
-	need += padded((size_t)n * sizeof(InTri));                                       // decoded triangles in input order
+	need += padded((size_t)n * sizeof(InTri)) + padded((size_t)n * 12) + padded((desc->num_meshes + 1) * sizeof(MeshSrc));   // staged triangles, doubled centroids, where each mesh is gathered from
 	need += 2 * padded((size_t)n * 8) + 2 * padded((size_t)n * 4);                  // keys a/b, vals a/b
 	need += padded(sort_words * 4) + padded(64) + padded(mesh_base.size() * 8);     // sort scratch, bounds, mesh_base
 	need += 2 * padded((size_t)n * 8) + padded((size_t)n * 12) + padded((size_t)n * 16) + padded((size_t)n * 4) + padded(16);   // lr, range, climbers, halves, arrive, root
@@ -1750,12 +1790,33 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 
 	// ---- 1 ingest ------------------------------------------------------------------
 	InTri *in_tris = ar.take<InTri>(n);
+	float *d_cent = ar.take<float>(3 * (size_t)n);
 	uint32_t *d_bounds = ar.take<uint32_t>(16);
+	// the scene keeps the original vertex indices in input order (for rtk_hit.vertex[].index: rtk_scene_side_arrays) only if some
+	// mesh HAS indices; with implicit indices everywhere they are 3 * triangle + corner
+	bool any_indexed = false;
+	for (size_t mi = 0; mi < desc->num_meshes; mi++) any_indexed = any_indexed || (desc->meshes[mi].num_triangles && (plans[mi].on_host_decode || plans[mi].idx_kind != 0));
+	rtk_dev_scene *ds = new rtk_dev_scene();
+	ds->device = device;
+	ds->num_cus = num_cus;
+	ds->mesh_base = mesh_base;
+	ds->side_ready = false;
+	uint32_t *d_vidx_in = nullptr;
+	if (any_indexed) {
+		void *pv = nullptr;
+		if (hipMalloc(&pv, 3 * (size_t)n * 4) != hipSuccess) { (void)hipGetLastError(); delete ds; rtk_set_error("device build: out of device memory (vertex indices)"); return nullptr; }
+		ds->allocs.push_back(pv); ds->total_bytes += 3 * (size_t)n * 4;
+		d_vidx_in = (uint32_t *)pv;
+		ds->d_vidx_in = d_vidx_in;
+	}
+	std::vector<MeshSrc> mesh_src(desc->num_meshes + 1, MeshSrc{ nullptr, 0ull });
+	// Every exit that gives the scene up from here on joins the build stream first (kernels already enqueued may still touch
+	// the workspace and the scene's allocations)
+#define INGEST_FAIL(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rtk_set_error("device build: %s failed: %s (line %d)", #expr, hipGetErrorString(e__), __LINE__); (void)hipStreamSynchronize(bs); rtk_dev_scene_free(ds); return nullptr; } } while (0)
 	// centroid bounds: min words start at all ones, max words at zero (ordered-uint encoding): two fills, nothing the host
 	// waits for. The decode kernels below take them in passing.
-	BUILD_CHECK(hipMemsetAsync(d_bounds, 0xff, 12, bs));
-	BUILD_CHECK(hipMemsetAsync(d_bounds + 3, 0, 12, bs));
-	bool bounds_pass_needed = false;          // some mesh came in as host-decoded records
+	INGEST_FAIL(hipMemsetAsync(d_bounds, 0xff, 12, bs));
+	INGEST_FAIL(hipMemsetAsync(d_bounds + 3, 0, 12, bs));
 	for (size_t mi = 0; mi < desc->num_meshes; mi++) {
 		const rtk_mesh *m = &desc->meshes[mi];
 		const MeshPlan &pl = plans[mi];
@@ -1771,29 +1832,36 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 				for (int c = 0; c < 9; c++) recs[t].p[c] = pos9[9 * t + c];
 				for (int c = 0; c < 3; c++) recs[t].vi[c] = vidx3[3 * t + c];
 			}
-			BUILD_CHECK(hipMemcpyAsync(in_tris + base, recs.data(), recs.size() * sizeof(InTri), hipMemcpyHostToDevice, bs));
-			BUILD_CHECK(hipStreamSynchronize(bs));      // (recs goes out of scope)
-			bounds_pass_needed = true;
+			INGEST_FAIL(hipMemcpyAsync(in_tris + base, recs.data(), recs.size() * sizeof(InTri), hipMemcpyHostToDevice, bs));
+			// centroids, vertex indices and centroid bounds of these records (the decode kernels below do this in passing)
+			const unsigned bblocks = (unsigned)std::min<size_t>((nt + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
+			hipLaunchKernelGGL(k_bounds, dim3(bblocks), dim3(BOUNDS_BLOCK), 0, bs, in_tris, base, (uint32_t)nt, d_bounds, d_cent, d_vidx_in);
+			INGEST_FAIL(hipStreamSynchronize(bs));      // (recs goes out of scope)
 			continue;
 		}
 		// raw buffers go to the device as they are; the decode runs there
 		const char *idx_ptr = pl.idx_src, *pos_ptr = pl.pos_src;
 		if (pl.ibytes) {
 			char *d = ar.take<char>(pl.ibytes);
-			BUILD_CHECK(upload_staged(d, pl.idx_src, pl.ibytes, bs));
+			INGEST_FAIL(upload_staged(d, pl.idx_src, pl.ibytes, bs));
 			idx_ptr = d;
 		}
 		if (pl.pbytes) {
 			char *d = ar.take<char>(pl.pbytes);
-			BUILD_CHECK(upload_staged(d, pl.pos_src, pl.pbytes, bs));
+			INGEST_FAIL(upload_staged(d, pl.pos_src, pl.pbytes, bs));
 			pos_ptr = d;
 		}
+		// implicit indices and float positions whose three components can be read as floats in place: gathered in place by k_emit_tris
+		static const bool allow_direct = !(getenv("RTK_AMD_BUILD_DIRECT") && atoi(getenv("RTK_AMD_BUILD_DIRECT")) == 0);
+		const bool direct = allow_direct && pl.idx_kind == 0 && !pl.f64 && (pl.pstride % 4u) == 0u && ((uintptr_t)pos_ptr % 4u) == 0u;
+		if (direct) mesh_src[mi] = MeshSrc{ pos_ptr, (unsigned long long)pl.pstride };
 		const unsigned iblocks = (unsigned)std::min<size_t>((nt + INGEST_BLOCK - 1) / INGEST_BLOCK, (size_t)num_cus);
-		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds, bs);
-		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds, bs);
-		else launch_ingest<2>(pl.f64, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_bounds, bs);
-		BUILD_CHECK(hipGetLastError());
+		if (pl.idx_kind == 0) launch_ingest<0>(pl.f64, direct, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_cent, d_vidx_in, d_bounds, bs);
+		else if (pl.idx_kind == 1) launch_ingest<1>(pl.f64, false, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_cent, d_vidx_in, d_bounds, bs);
+		else launch_ingest<2>(pl.f64, false, iblocks, pos_ptr, pl.pstride, idx_ptr, pl.istride, (uint32_t)nt, base, in_tris, d_cent, d_vidx_in, d_bounds, bs);
+		INGEST_FAIL(hipGetLastError());
 	}
+#undef INGEST_FAIL
 	stage("ingest");
 
 	BuildParams bp;
@@ -1826,14 +1894,10 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	}
 	uint32_t *vals_a = packed ? nullptr : ar.take<uint32_t>(n), *vals_b = packed ? nullptr : ar.take<uint32_t>(n);
 	uint32_t *sort_scratch = ar.take<uint32_t>(sort_words);
-	unsigned long long *d_mesh_base = ar.take<unsigned long long>(mesh_base.size());
+	MeshSrc *d_mesh_src = ar.take<MeshSrc>(desc->num_meshes + 1);
 	{
-		if (bounds_pass_needed) {
-			const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK, (size_t)num_cus);
-			hipLaunchKernelGGL(k_bounds, dim3(blocks), dim3(BOUNDS_BLOCK), 0, bs, in_tris, n, d_bounds);
-		}
-		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, n, d_bounds, keys_a, vals_a, 63u - (packed ? packed_bits : key_bits));
-		BUILD_CHECK(hipGetLastError());
+		hipLaunchKernelGGL(k_morton, dim3((n + 255u) / 256u), dim3(256), 0, bs, d_cent, n, d_bounds, keys_a, vals_a, 63u - (packed ? packed_bits : key_bits));
+		if (hipGetLastError() != hipSuccess) { rtk_set_error("device build: morton launch failed"); (void)hipStreamSynchronize(bs); rtk_dev_scene_free(ds); return nullptr; }
 	}
 	stage("morton");
 
@@ -1842,15 +1906,11 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	                         : rtk_sort_pairs_async(keys_a, keys_b, vals_a, vals_b, n, key_bits, sort_scratch, bs);
 	const unsigned long long *keys = in_b ? keys_b : keys_a;      // packed: all different (the index is part of the word), in ascending order
 	const uint32_t *vals = packed ? nullptr : (in_b ? vals_b : vals_a);
-	BUILD_CHECK(hipGetLastError());
+	if (hipGetLastError() != hipSuccess) { rtk_set_error("device build: sort launch failed"); (void)hipStreamSynchronize(bs); rtk_dev_scene_free(ds); return nullptr; }
 	stage("sort");
 
 	// ---- 5 emit: final triangle records in Morton order ----------------------------------
 	const std::vector<unsigned long long> mb(mesh_base.begin(), mesh_base.end());   // source of an async copy: lives until the final sync
-	rtk_dev_scene *ds = new rtk_dev_scene();
-	ds->device = device;
-	ds->num_cus = num_cus;
-	ds->mesh_base = mesh_base;
 	bool side_busy = false;             // kernels on ws.side may still be reading the workspace
 	// Every exit that gives the scene up joins BOTH streams first: kernels already enqueued may still read or write the
 	// persistent workspace (the next build on this device reuses it as soon as the workspace mutex is released) and the
@@ -1872,20 +1932,18 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		ds->total_bytes += bytes;
 		return (char *)p;
 	};
-	// one allocation for the triangle records and their side arrays
-	const size_t o_vidx = padded((size_t)n * sizeof(DevTri)), o_pslot = o_vidx + padded(3 * (size_t)n * 4), o_smesh = o_pslot + padded((size_t)n * 4),
-		o_stri = o_smesh + padded((size_t)n * 4), tri_block = o_stri + padded((size_t)n * 4);
+	// the triangle records; the mesh table (a few words the scene keeps: rtk_scene_side_arrays reads it)
+	const size_t o_mb = padded((size_t)n * sizeof(DevTri)), tri_block = o_mb + padded(mb.size() * 8);
 	char *tri_mem = dev_alloc(tri_block);
 	if (!tri_mem) return fail("out of device memory");
 	DevTri *d_tris = (DevTri *)tri_mem;
-	uint32_t *d_vertex_index = (uint32_t *)(tri_mem + o_vidx);
-	uint32_t *d_prim_slot = (uint32_t *)(tri_mem + o_pslot);
-	uint32_t *d_slot_mesh = (uint32_t *)(tri_mem + o_smesh);
-	uint32_t *d_slot_tri = (uint32_t *)(tri_mem + o_stri);
+	unsigned long long *d_mesh_base = (unsigned long long *)(tri_mem + o_mb);
+	ds->d_mesh_base = d_mesh_base;
 	{
-		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, bs) != hipSuccess) return fail("copy");
-		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, vals, keys, n, d_mesh_base,
-			(uint32_t)desc->num_meshes, d_tris, d_vertex_index, d_prim_slot, d_slot_mesh, d_slot_tri);
+		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, bs) != hipSuccess ||
+			hipMemcpyAsync(d_mesh_src, mesh_src.data(), mesh_src.size() * sizeof(MeshSrc), hipMemcpyHostToDevice, bs) != hipSuccess) return fail("copy");
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, d_mesh_src, vals, keys, n, d_mesh_base,
+			(uint32_t)desc->num_meshes, d_tris);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
 	}
 	stage("emit");
@@ -2066,10 +2124,10 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	rtk_quantize_finish(ds);
 
 	ds->view.tris = d_tris;
-	ds->view.vertex_index = d_vertex_index;
-	ds->view.prim_slot = d_prim_slot;
-	ds->view.slot_mesh = d_slot_mesh;
-	ds->view.slot_tri = d_slot_tri;
+	ds->view.vertex_index = nullptr;           // (the four side arrays: rtk_scene_side_arrays, on first use)
+	ds->view.prim_slot = nullptr;
+	ds->view.slot_mesh = nullptr;
+	ds->view.slot_tri = nullptr;
 	ds->view.num_nodes = total_nodes;
 	ds->view.num_tris = n;
 	ds->view.num_prims = n;
@@ -2106,6 +2164,40 @@ extern "C" rtk_dev_scene *rtk_dev_scene_build(const rtk_scene_desc *desc)
 	return ds;
 }
 
+// The four side arrays of a device-built scene, made when something first needs them (the expansion of hit records into rtk_hit,
+// rtk_trace_ray's one-ray kernel, the validator, the exporter). One kernel over the triangle records; the calling thread waits
+// for it that one time, so that launches on any other stream may use the arrays as soon as this returns.
+int rtk_scene_side_arrays(const rtk_dev_scene *ds_c, hipStream_t stream)
+{
+	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
+	if (!ds) return RTK_AMD_ERR_BAD_ARG;
+	std::lock_guard<std::mutex> lock(ds->side_mutex);
+	if (ds->side_ready) return RTK_AMD_OK;
+	const size_t n = ds->view.num_tris, np = ds->view.num_prims;
+	const size_t o_pslot = padded(3 * n * 4), o_smesh = o_pslot + padded(np * 4), o_stri = o_smesh + padded(n * 4), total = o_stri + padded(n * 4);
+	void *mem = nullptr;
+	RTK_HIP_CHECK(hipMalloc(&mem, total), RTK_AMD_ERR_OOM);
+	char *base = (char *)mem;
+	uint32_t *vertex_index = (uint32_t *)base, *prim_slot = (uint32_t *)(base + o_pslot), *slot_mesh = (uint32_t *)(base + o_smesh), *slot_tri = (uint32_t *)(base + o_stri);
+	if (n) {
+		hipLaunchKernelGGL(k_side_arrays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ds->view.tris, (uint32_t)n, ds->d_mesh_base, ds->d_vidx_in,
+			vertex_index, prim_slot, slot_mesh, slot_tri);
+		if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+			rtk_set_error("rtk_scene_side_arrays: %s", hipGetErrorString(hipGetLastError()));
+			(void)hipFree(mem);
+			return RTK_AMD_ERR_HIP;
+		}
+	}
+	ds->allocs.push_back(mem);
+	ds->total_bytes += total;
+	ds->view.vertex_index = vertex_index;
+	ds->view.prim_slot = prim_slot;
+	ds->view.slot_mesh = slot_mesh;
+	ds->view.slot_tri = slot_tri;
+	ds->side_ready = true;
+	return RTK_AMD_OK;
+}
+
 // =====================================================================================
 // export: device BVH -> reference-format blob (writer intent rtk.c:1719-1774)
 // =====================================================================================
@@ -2128,6 +2220,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
 bool download(const rtk_dev_scene *ds, ExportPlan &ep)
 {
+	if (rtk_scene_side_arrays(ds, nullptr) != RTK_AMD_OK) return false;
 	const DevSceneView &v = ds->view;
 	ep.nodes.resize(v.num_nodes);
 	ep.tris.resize(v.num_tris);

@@ -136,7 +136,16 @@ struct rtk_dev_scene {
 	std::mutex scratch_mutex;
 	std::vector<LaunchScratch *> scratch;
 	int num_cus = 0;
+	// Device-built scenes make the four side arrays of the view (vertex_index, prim_slot, slot_mesh, slot_tri: what the expansion of
+	// hit records, the validator and the exporter read -- never a traversal) on first use, not in every build: 52 of the 100
+	// bytes per triangle the build's emit kernel wrote, one of them scattered (rtk_scene_side_arrays, rtk_build.hip).
+	std::mutex side_mutex;
+	bool side_ready = true;                    // (uploads arrive with the arrays)
+	const uint32_t *d_vidx_in = nullptr;       // [3 * prim + k] original vertex indices in input order; NULL: every mesh has implicit indices
+	const unsigned long long *d_mesh_base = nullptr;   // num_meshes + 1, on the device
 };
+// makes the side arrays if they are not there yet (synchronises `stream` the one time it has to work)
+int rtk_scene_side_arrays(const rtk_dev_scene *ds, hipStream_t stream);
 
 // -- error plumbing (rtk_capi.hip) --
 void rtk_set_error(const char *fmt, ...);

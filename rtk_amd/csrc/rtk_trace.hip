@@ -1320,6 +1320,7 @@ int rtk_launch_expand(const rtk_dev_scene *ds_c, const rtk_hit_record *d_records
 			return RTK_AMD_ERR_BAD_ARG;
 		}
 	}
+	if (d_hits && rtk_scene_side_arrays(ds, stream) != RTK_AMD_OK) return RTK_AMD_ERR_OOM;
 	const unsigned long long *status_word = nullptr;
 	if (h_status) {
 		// the error word of the launches on this stream (rtk_launch_trace has made the scratch set)
@@ -1350,6 +1351,7 @@ int rtk_launch_trace_one(const rtk_dev_scene *ds, const rtk_ray *d_ray, rtk_hit 
 		rtk_set_error("rtk_trace_ray: the one-ray kernel addresses nodes and triangles with 32-bit byte offsets (scene: %u nodes, %u triangles)", ds->view.num_nodes, ds->view.num_tris);
 		return RTK_AMD_ERR_UNSUPPORTED;
 	}
+	if (rtk_scene_side_arrays(ds, stream) != RTK_AMD_OK) return RTK_AMD_ERR_OOM;
 	hipLaunchKernelGGL(rtk_trace_one_kernel, dim3(1), dim3(64), 0, stream, ds->view, *d_ray, d_hit, d_mask, h_status, ticket);
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;

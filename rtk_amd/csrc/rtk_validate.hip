@@ -147,6 +147,7 @@ __global__ void k_check_counts(DevSceneView sc, const uint32_t *node_seen, const
 extern "C" int rtk_dev_scene_validate(const rtk_dev_scene *ds, rtk_dev_scene_check *out)
 {
 	if (!ds || !out) { rtk_set_error("rtk_dev_scene_validate: NULL argument"); return RTK_AMD_ERR_BAD_ARG; }
+	if (rtk_scene_side_arrays(ds, nullptr) != RTK_AMD_OK) return RTK_AMD_ERR_OOM;
 	const DevSceneView &v = ds->view;
 	const size_t words = (size_t)v.num_tris + v.num_nodes + v.num_prims + 16;
 	uint32_t *d_seen = nullptr;
