@@ -704,10 +704,11 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 			cur_ref = parent;
 			s_bin[k] = cur;
 		}
-		climbers[i] = left_over;
-		// ... and where pass 2 finds the tile's climbers without looking at every triangle: their positions, packed at the
-		// start of the tile's stretch of climb_idx (any order: the tree does not depend on who climbs first)
-		if (left_over.cur_ref != INT_MIN) climb_idx[lo + (int)atomicAdd(&s_nclimb, 1u)] = i;
+		// a climber is stored at the leaf that carried it, and where pass 2 and the tile collapse find the tile's climbers without
+		// looking at every triangle: their positions, packed at the start of the tile's stretch of climb_idx (any order: the tree
+		// does not depend on who climbs first). (Round 4 wrote all 1024 records of a tile, 12 bytes per triangle, and both
+		// collapse kernels read them all back to find the two dozen that are there.)
+		if (left_over.cur_ref != INT_MIN) { climbers[i] = left_over; climb_idx[lo + (int)atomicAdd(&s_nclimb, 1u)] = i; }
 	}
 	__syncthreads();
 	if (t == 0) tile_nclimb[blockIdx.x] = s_nclimb;
@@ -1173,7 +1174,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 // 64-thread counting kernel, 22 us of a tile's 118 in k_collapse_tile.)
 template <int THREADS>
 __device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers,
-	int2 *s_lr, float *s_area, uint16_t *s_start, int *s_roots, uint32_t *s_nroots)
+	const int *climb_idx, uint32_t nclimb, int2 *s_lr, float *s_area, uint16_t *s_start, int *s_roots, uint32_t *s_nroots)
 {
 	constexpr int ITER = REFIT_TILE / THREADS;
 	const int t = (int)threadIdx.x;
@@ -1181,14 +1182,15 @@ __device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const 
 	int2 v_lr[ITER];
 	uint2 v_rg[ITER];
 	float v_a[ITER];
-	int v_cl[ITER];
 #pragma unroll
 	for (int q = 0; q < ITER; q++) {
 		const int i = lo + t + q * THREADS;
 		const int ic = i < hi ? i : (hi > lo ? hi - 1 : lo);       // (a position that exists: the values of positions beyond the tile are not used)
 		v_lr[q] = lr[ic]; v_a[q] = area[ic]; v_rg[q] = range[ic];
-		v_cl[q] = climbers[i <= hi ? i : hi].cur_ref;
 	}
+	// the subtrees the tile's climbers carried to its borders (a few to a few dozen: their positions are listed per tile)
+	int v_cl = INT_MIN;
+	if ((uint32_t)t < nclimb) v_cl = climbers[climb_idx[lo + t]].cur_ref;
 #pragma unroll
 	for (int q = 0; q < ITER; q++) {
 		const int k = t + q * THREADS, i = lo + k;
@@ -1201,13 +1203,13 @@ __device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const 
 		if (s_start) s_start[k] = (uint16_t)((int)rg.x >= lo ? (int)rg.x - lo : 0);
 	}
 	__syncthreads();
+	for (uint32_t j = (uint32_t)t; j < nclimb; j += THREADS) {
+		const int a = j == (uint32_t)t ? v_cl : climbers[climb_idx[lo + (int)j]].cur_ref;
+		if (a >= 0 && s_area[a - lo] > 0.0f) s_roots[atomicAdd(s_nroots, 1u)] = a;
+	}
 #pragma unroll
 	for (int q = 0; q < ITER; q++) {
 		const int k = t + q * THREADS, i = lo + k;
-		if (i <= hi) {
-			const int a = v_cl[q];
-			if (a >= 0 && s_area[a - lo] > 0.0f) s_roots[atomicAdd(s_nroots, 1u)] = a;
-		}
 		if (i < hi && s_area[k] <= -2.0f) {
 			const int2 ch = s_lr[k];
 			// (left child: sorted range [start, i]; right child: [i + 1, end]. At most one of them lies inside the tile: the
@@ -1273,7 +1275,8 @@ __device__ __forceinline__ uint32_t tile_bfs(int lo, const int2 *s_lr, const flo
 	return tail;
 }
 
-__global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers, uint32_t *tile_count)
+__global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers, const int *climb_idx,
+	const uint32_t *tile_nclimb, uint32_t *tile_count)
 {
 	__shared__ int2 s_lr[REFIT_TILE];
 	__shared__ float s_area[REFIT_TILE];
@@ -1282,7 +1285,7 @@ __global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const 
 	__shared__ uint32_t s_nroots;
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
-	tile_load<64>(lo, hi, lr, range, area, climbers, s_lr, s_area, nullptr, s_roots, &s_nroots);
+	tile_load<64>(lo, hi, lr, range, area, climbers, climb_idx, tile_nclimb[blockIdx.x], s_lr, s_area, nullptr, s_roots, &s_nroots);
 	if (threadIdx.x < 64u) {
 		const uint32_t count = tile_bfs(lo, s_lr, s_area, nullptr, s_roots, s_nroots, nullptr, s_q, nullptr, nullptr, nullptr);
 		if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
@@ -1290,8 +1293,8 @@ __global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const 
 }
 
 __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, int n, const int2 *lr, const uint2 *range, const BinNode *bin, const float *area,
-	const Climb *climbers, const unsigned long long *tile_parent, const uint32_t *tile_base, uint32_t node_offset, DevNode *nodes, DevNodeQ *qnodes,
-	uint32_t node_cap, DevSceneConsts *consts, uint32_t *depth_word)
+	const Climb *climbers, const int *climb_idx, const uint32_t *tile_nclimb, const unsigned long long *tile_parent, const uint32_t *tile_base, uint32_t node_offset,
+	DevNode *nodes, DevNodeQ *qnodes, uint32_t node_cap, DevSceneConsts *consts, uint32_t *depth_word)
 {
 	__shared__ int2 s_lr[REFIT_TILE];          //  8 KB
 	__shared__ float s_area[REFIT_TILE];       //  4 KB
@@ -1304,7 +1307,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, in
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
 	const int t = (int)threadIdx.x;
-	tile_load<TILE_THREADS>(lo, hi, lr, range, area, climbers, s_lr, s_area, s_start, s_roots, &s_nroots);
+	tile_load<TILE_THREADS>(lo, hi, lr, range, area, climbers, climb_idx, tile_nclimb[blockIdx.x], s_lr, s_area, s_start, s_roots, &s_nroots);
 	for (int k = t; k < REFIT_TILE; k += TILE_THREADS) s_base[k] = 0u;
 	__syncthreads();
 	if (t < 64) {
@@ -1991,7 +1994,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		}
 		const bool forked = ws.side && hipEventRecord(ws.fork, bs) == hipSuccess && hipStreamWaitEvent(ws.side, ws.fork, 0) == hipSuccess;
 		const hipStream_t cs = forked ? ws.side : bs;
-		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, cs, (int)n, d_lr, d_range, d_area, d_climbers, d_tile_count);
+		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, cs, (int)n, d_lr, d_range, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_tile_count);
 		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, cs, d_tile_count, num_tiles, d_tile_base);
 		if (forked) {
 			side_busy = true;
@@ -2063,7 +2066,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 			if (!run_collapse(d_nodes_, (uint32_t)node_cap, (uint64_t)num_tiles * 16u)) return fail("collapse");
 			const uint32_t top_nodes = h_state.total_nodes;
 			if (side_busy && hipStreamWaitEvent(bs, ws.join, 0) != hipSuccess) return fail("stream wait");      // the tile counts and bases are there
-			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, bs, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_climbers, d_tile_parent,
+			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, bs, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_tile_parent,
 				d_tile_base, top_nodes, d_nodes_, (DevNodeQ *)(d_nodes_ + node_cap), (uint32_t)node_cap, consts, d_depth_word);
 			if (hipGetLastError() != hipSuccess ||
 				hipMemcpyAsync(&h_tail[0], d_tile_base + num_tiles, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
