@@ -459,7 +459,7 @@ def main():
                   no_packet=args.no_packet, sort_rays=args.sort_rays)
     if args.workload == "coherent":
         rays = synth.rays_pinhole(W, H, jitter=synth.frame_jitter(rank))
-        opts = api.make_opts(image=None if args.no_tiling else (W, H), **common)
+        opts = api.make_opts(image=None if args.no_tiling else (W, H), no_detect=args.no_tiling, **common)
         workload = "config2: 1M-tri soup (seed 1, spread 0.02), %dx%d coherent pinhole primary rays" % (W, H)
         metric = "Mrays/sec (primary, closest-hit) on 1M-tri scene"
     elif args.workload == "incoherent":
@@ -584,6 +584,29 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms = [ev_region[0].elapsed_time(ev_region[1]) / max(1, args.steps)]
 
+    # ---- the same frame WITHOUT the image hint (opts = NULL, what a host that only knows rays and records passes): the library looks
+    # at the batch (two small launches and a wait per call), finds the image and runs the same kernels; records must be the same bytes
+    no_hint = None
+    if packet_kernel and world == 1 and args.steps:
+        ref_out = d_outs[(args.steps - 1) % len(d_outs)].clone()
+        k2 = max(3, args.steps // 4)
+        ds.trace_device(d_rays, n, d_outs[0], None)
+        sync()
+        per_call = []
+        for _ in range(k2):
+            t2 = time.perf_counter()
+            ds.trace_device(d_rays, n, d_outs[0], None)
+            per_call.append(time.perf_counter() - t2)
+        sync()
+        # (every un-hinted call waits for its stream once -- the look's verdict --, so the host's time from call to call IS the step
+        # time: the first call of the loop only enqueues behind nothing and is left out)
+        dt = sum(per_call[1:])
+        k2 -= 1
+        no_hint = {"value": round(n * k2 / dt / 1e6, 2), "unit": "Mrays/s", "steps": k2, "ms_per_step": round(dt / k2 * 1e3, 4),
+                   "records_identical_to_the_hinted_run": bool(torch.equal(ref_out, d_outs[0])),
+                   "what": "rtk_dev_trace_rays(opts = NULL) on the same rays: the image is detected per call (k_detect_row, k_detect_check, one stream wait)"}
+        d_outs[(args.steps - 1) % len(d_outs)].copy_(ref_out)
+        del ref_out
     other_modes = {}
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -679,6 +702,7 @@ def main():
                    "exposed_exchange_ms_per_step": ({how: round(((elapsed if how == mode else other_modes[how]) - elapsed_no_gather) / args.steps * 1e3, 4)
                                                      for how in ("striped", "root") if (how == mode or how in other_modes)}
                                                     if (world > 1 and elapsed_no_gather) else None),
+                   "without_image_hint": no_hint,
                    "launch": "static" if args.static else "persistent",
                    "ray_order": "RTK_TRACE_SORT_RAYS: re-ordered by origin cell inside every timed step" if args.sort_rays else "as given",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},

@@ -77,7 +77,8 @@ typedef struct rtk_trace_opts {
 	uint32_t struct_size;      /* sizeof(rtk_trace_opts) */
 	uint32_t flags;            /* RTK_TRACE_* */
 	uint32_t image_width;      /* if both non-zero and width*height == n: rays are a   */
-	uint32_t image_height;     /* row-major image; lanes are mapped to 8x8 pixel tiles  */
+	uint32_t image_height;     /* row-major image; lanes are mapped to 8x8 pixel tiles. Without it (or with NULL options) a closest-hit batch of whole
+	                              64x64-pixel blocks is LOOKED AT: a regular step from ray to ray that jumps at the same distance every time is an image */
 	uint32_t refill_min;       /* 0 = default; idle lanes needed before a wave refills  */
 	uint32_t blocks_per_cu;    /* 0 = default; persistent grid size                     */
 	uint32_t node_exit;        /* 0 = default; see DESIGN.md 3.1 (divergence control)   */
@@ -89,6 +90,8 @@ typedef struct rtk_trace_opts {
 #define RTK_TRACE_NO_ENTRIES 32u  /* image-shaped batch: every tile starts at the root, no per-block entry lists (A/B only) */
 #define RTK_TRACE_NO_BEAM 64u     /* image-shaped batch: rtk_packet_hot (per-lane slab tests) instead of the beam kernels (A/B only) */
 #define RTK_TRACE_ONE_TILE_BEAM 128u /* image-shaped batch: rtk_packet_beam (one tile per wave) instead of rtk_packet_beam2 (A/B only) */
+#define RTK_TRACE_NO_DETECT 256u   /* no image hint given: do not look whether the batch is a row-major image anyway (A/B; saves the two small launches
+                                     and the wait of the look when the caller knows its rays are not an image) */
 #define RTK_TRACE_SORT_RAYS 4u   /* reorder the batch by (origin cell, direction octant) before tracing; hits
                                     still land in input order. Pays off for large incoherent batches. */
 
@@ -201,6 +204,12 @@ int rtk_dev_trace_rays_any_filtered(const rtk_dev_scene *ds, const rtk_ray *d_ra
 /* Waits for `stream` and reports whether a launch of this scene on it overflowed a traversal stack
  * (RTK_AMD_ERR_BAD_SCENE; impossible for a validated tree -- the push is dropped, never written out of bounds). */
 int rtk_dev_trace_status(const rtk_dev_scene *ds, void *stream);
+
+/* Is the device-resident batch a row-major image (a regular step from ray to ray -- origin and direction -- that jumps at the same
+ * distance every time)? *width, *height = its shape, or 0, 0. What rtk_dev_trace_rays does by itself for a closest-hit batch that
+ * comes without the image hint (two small launches and a wait for `stream`, ~20 us): a host that traces many frames of one
+ * shape asks once and passes the shape in rtk_trace_opts afterwards. A wrong answer can only cost speed, never a hit. */
+int rtk_dev_detect_image(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, uint32_t *width, uint32_t *height, void *stream);
 
 /* Same result as rtk_dev_trace_rays, plus visit counts. Synchronous; not for timing. */
 int rtk_dev_trace_rays_counted(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,

@@ -87,7 +87,7 @@ RTK_AMD_H_SYMBOLS = ["rtk_amd_last_error", "rtk_amd_device_count", "rtk_amd_set_
                      "rtk_dev_scene_upload", "rtk_dev_scene_build", "rtk_dev_scene_free", "rtk_dev_scene_get_info",
                      "rtk_dev_scene_mesh_base", "rtk_dev_scene_primitive_order", "rtk_dev_scene_export_size", "rtk_dev_scene_export",
                      "rtk_dev_trace_rays", "rtk_dev_trace_rays_any", "rtk_dev_expand_hits",
-                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_dev_trace_rays_packet_counted", "rtk_trace_rays", "rtk_amd_forget_scene",
+                     "rtk_dev_trace_rays_counted", "rtk_dev_trace_rays_any_counted", "rtk_dev_trace_rays_packet_counted", "rtk_dev_detect_image", "rtk_trace_rays", "rtk_amd_forget_scene",
                      "rtk_dev_scene_validate", "rtk_amd_release_workspace", "rtk_dev_scene_upload_buffer",
                      "rtk_dev_trace_rays_filtered", "rtk_dev_trace_rays_any_filtered", "rtk_dev_trace_status",
                      "rtk_trace_rays_filter", "rtk_amd_shard_range", "rtk_mgpu_create", "rtk_mgpu_destroy", "rtk_mgpu_num_devices",
@@ -213,7 +213,7 @@ def to_device(a):
 
 
 def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit=0, no_packet=False, sort_rays=False, exact_nodes=False,
-              no_asm=False, no_entries=False, no_beam=False, one_tile_beam=False):
+              no_asm=False, no_entries=False, no_beam=False, one_tile_beam=False, no_detect=False):
     o = TraceOpts()
     o.struct_size = C.sizeof(TraceOpts)
     o.flags = (RTK_TRACE_STATIC if static else 0) | (RTK_TRACE_NO_PACKET if no_packet else 0) | (RTK_TRACE_SORT_RAYS if sort_rays else 0)
@@ -227,6 +227,8 @@ def make_opts(image=None, static=False, refill_min=0, blocks_per_cu=0, node_exit
         o.flags |= 64      # RTK_TRACE_NO_BEAM
     if one_tile_beam:
         o.flags |= 128     # RTK_TRACE_ONE_TILE_BEAM
+    if no_detect:
+        o.flags |= 256     # RTK_TRACE_NO_DETECT
     if image:
         o.image_width, o.image_height = int(image[0]), int(image[1])
     o.refill_min = refill_min
@@ -435,6 +437,14 @@ class DeviceScene:
                "rtk_dev_trace_rays_counted")
         return d_rec.cpu().numpy().view(HIT_RECORD_DTYPE), ctr.as_dict()
 
+
+    def detect_image(self, rays):
+        """rtk_dev_detect_image: (width, height) of the row-major image the batch is, or (0, 0)."""
+        rays = np.ascontiguousarray(rays)
+        d_rays = to_device(rays)
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().rtk_dev_detect_image(self.handle, C.c_void_p(d_rays.data_ptr()), C.c_size_t(rays.shape[0]), C.byref(w), C.byref(h), _stream_ptr()), "rtk_dev_detect_image")
+        return int(w.value), int(h.value)
 
     def trace_packet_counted(self, rays, opts):
         """rtk_dev_trace_rays_packet_counted: (records, counters of the hand-written packet kernel itself)."""

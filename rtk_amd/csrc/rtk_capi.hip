@@ -154,6 +154,12 @@ extern "C" int rtk_dev_trace_rays_packet_counted(const rtk_dev_scene *ds, const 
 	return rtk_launch_trace(ds, d_rays, n, d_hits, nullptr, opts, nullptr, false, nullptr, nullptr, nullptr, nullptr, 0, out);
 }
 
+extern "C" int rtk_dev_detect_image(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, uint32_t *width, uint32_t *height, void *stream)
+{
+	if (!ds || !width || !height || (!d_rays && n)) { rtk_set_error("rtk_dev_detect_image: NULL argument"); return RTK_AMD_ERR_BAD_ARG; }
+	return rtk_detect_image(ds, d_rays, n, (hipStream_t)stream, width, height);
+}
+
 extern "C" int rtk_dev_trace_status(const rtk_dev_scene *ds, void *stream)
 {
 	return rtk_trace_status(ds, (hipStream_t)stream);

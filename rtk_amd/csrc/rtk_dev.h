@@ -113,6 +113,7 @@ struct LaunchScratch {
 	size_t sort_capacity = 0;                   // rays
 	void *d_entries = nullptr;                  // packet kernels: entry lists of the image's 64x64-pixel blocks (PkBlockEntries), grown on demand
 	size_t entries_capacity = 0;                // blocks
+	volatile uint32_t *h_verdict = nullptr;     // pinned: where k_detect_check leaves (width, height) of an image nobody announced
 	uint32_t *d_leftover = nullptr;             // tiles the assembly packet kernel hands to the C++ one, grown on demand
 	size_t leftover_capacity = 0;               // tiles
 };
@@ -194,6 +195,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, r
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
 	const rtk_dev_filter *filter = nullptr, rtk_hit_record *d_cand = nullptr, uint32_t *d_cand_count = nullptr, uint32_t cand_k = 0,
 	rtk_packet_counters *pk_counted = nullptr);
+int rtk_detect_image(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n, hipStream_t stream, uint32_t *w_out, uint32_t *h_out);
 int rtk_trace_status(const rtk_dev_scene *ds, hipStream_t stream);
 void rtk_scratch_free(LaunchScratch *s);
 void rtk_scene_drop_stream(rtk_dev_scene *ds, hipStream_t stream);   // the stream is about to be destroyed (and has been synchronised)

@@ -287,3 +287,25 @@ def test_exotic_rays_bit_exact_on_the_same_bvh(api, oracle, scene1):
         rec = ds_dev.trace(odd, opts=opts, full=False)
         assert api.lib().rtk_dev_trace_status(ds_dev.handle, None) == 0
         assert (rec["prim"][0::2] == 0xFFFFFFFF).all()                 # NaN limit: nothing compares less than it
+
+
+def test_an_image_is_recognised_without_the_hint(api, scene1):
+    """The reference's interface has no notion of an image (rtk.h:129): a batch that IS a row-major image is recognised by its
+    regular step (rtk_dev_detect_image; rtk_dev_trace_rays does the same look when no hint comes) and gets the packet kernels; the
+    records are the same bytes on every path. Batches that are not images, or not whole 64x64 blocks, go the way they always did."""
+    ds = api.DeviceScene.build([dict(positions=synth.scene_for_config(1))])
+    frame = synth.rays_pinhole(256, 128)
+    assert ds.detect_image(frame) == (256, 128)
+    assert ds.detect_image(synth.rays_pinhole(192, 320, jitter=synth.frame_jitter(3))) == (192, 320)
+    assert ds.detect_image(synth.rays_pinhole(200, 96)) == (200, 96)            # recognised, but not whole blocks: traced per lane
+    assert ds.detect_image(synth.rays_incoherent(32768)) == (0, 0)
+    assert ds.detect_image(synth.rays_config1(32768)) == (0, 0)
+    two = np.concatenate([synth.rays_pinhole(128, 64), synth.rays_pinhole(256, 96)])     # two images glued together are not one
+    assert ds.detect_image(two) == (0, 0)
+    hinted = ds.trace(frame, opts=api.make_opts(image=(256, 128)), full=False)
+    for opts in (None, api.make_opts(), api.make_opts(no_detect=True)):
+        assert ds.trace(frame, opts=opts, full=False).tobytes() == hinted.tobytes()
+    # the look really switches kernels: with it the packet kernels' tile counter moves (the counting call needs the hint, so the
+    # check is indirect: the per-lane kernel and the packet kernel agree, and a batch that is no image is untouched by the look)
+    inc = synth.rays_incoherent(32768)
+    assert ds.trace(inc, full=False).tobytes() == ds.trace(inc, opts=api.make_opts(no_detect=True), full=False).tobytes()
