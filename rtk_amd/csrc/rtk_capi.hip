@@ -418,7 +418,7 @@ thread_local HostCtx t_ctx;
 
 // One piece (n <= chunk capacity), first half: rays up, trace (optionally restricted to candidates after h_after),
 // expand, hits and mask on their way down -- everything enqueued on the context's stream, nothing waited for.
-bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n, bool want_hits, bool with_after)
+bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n, bool want_hits, bool with_after, const rtk_trace_opts *opts = nullptr)
 {
 	memcpy(c.h_rays, rays, n * sizeof(rtk_ray));
 	// Small pieces skip the copy engines altogether: the pinned staging memory is visible to the device, so the kernels
@@ -434,7 +434,7 @@ bool enqueue_piece(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *rays, size_t n,
 		if (hipMemcpyAsync(c.d_after, c.h_after, n * sizeof(rtk_hit_record), hipMemcpyHostToDevice, c.stream) != hipSuccess) { rtk_set_error("rtk_trace_rays: H2D copy failed"); return false; }
 		f.d_after = c.d_after;
 	}
-	if (rtk_launch_trace(ds, d_rays, n, c.d_rec, nullptr, nullptr, c.stream, false, nullptr, with_after ? &f : nullptr) != RTK_AMD_OK) return false;
+	if (rtk_launch_trace(ds, d_rays, n, c.d_rec, nullptr, opts, c.stream, false, nullptr, with_after ? &f : nullptr) != RTK_AMD_OK) return false;
 	c.status_mirrored = false;
 	if (zero_copy) {
 		c.ticket_in_flight = 0;
@@ -506,6 +506,42 @@ size_t trace_one(rtk_dev_scene *ds, HostCtx &c, const rtk_ray *ray, rtk_hit *hit
 	return m ? 1 : 0;
 }
 
+// The look of rtk_dev_trace_rays for an un-announced image (rtk_trace.hip, k_detect_row / k_detect_check), on host rays: the step
+// from ray to ray (origin and direction) is regular and jumps at the same distance every time. A batch of host rays is cut into
+// pieces for the staging buffers; an image is cut into bands of whole 64-pixel rows so that every piece is an image the packet
+// kernels take.
+bool host_step_jumps(const rtk_ray *rays, size_t i)
+{
+	const float *a = reinterpret_cast<const float *>(rays + i - 1), *b = reinterpret_cast<const float *>(rays + i), *c = reinterpret_cast<const float *>(rays + i + 1);
+	float m = 0.0f, dmax = 0.0f;
+	for (int k = 0; k < 6; k++) {
+		const float s0 = b[k] - a[k], s1 = c[k] - b[k];
+		m = fabsf(s0) > m ? fabsf(s0) : m;
+		dmax = fabsf(s1 - s0) > dmax ? fabsf(s1 - s0) : dmax;
+	}
+	return !(dmax <= 8.0f * m);
+}
+
+void host_detect_image(const rtk_ray *rays, size_t n, uint32_t *w_out, uint32_t *h_out)
+{
+	*w_out = *h_out = 0u;
+	if (n < 4 || n > 0x40000000ull) return;
+	const size_t limit = n < ((size_t)1 << 17) ? n : ((size_t)1 << 17);
+	size_t first = 0;
+	for (size_t i = 1; i + 1 < limit; i++) if (host_step_jumps(rays, i)) { first = i; break; }
+	const size_t w = first + 1;
+	if (!first || w < 64 || (n % w) != 0 || n / w < 2 || n / w > 0xffffffffull) return;
+	const size_t rows = n / w, stride = rows > 256 ? rows / 256 : 1;
+	for (size_t k = 0; k < 256; k++) {
+		const size_t r = k * stride;
+		if (r + 1 >= rows) break;
+		if (!host_step_jumps(rays, (r + 1) * w - 1)) return;
+		for (size_t q = 1; q < 4; q++) if (host_step_jumps(rays, r * w + q * (w / 4))) return;
+	}
+	*w_out = (uint32_t)w;
+	*h_out = (uint32_t)rows;
+}
+
 std::atomic<int> g_test_fail_calls{0};
 // Fault injection for the tests of the per-ray calls' failure reporting. Not in the installed header; a no-op unless the process
 // was started with RTK_AMD_TEST_HOOKS=1 (read once): no code of a production host can make its traces fail through it.
@@ -515,7 +551,7 @@ extern "C" void rtk_amd_test_fail_next_calls(int calls)
 	if (armed) g_test_fail_calls.store(calls > 0 ? calls : 0);
 }
 thread_local HostCtx t_ctx2;                    // second staging set (own stream) for pipelined host-pointer batches
-const size_t PIPE_CHUNK = (size_t)1 << 15;      // rays per piece when a batch is pipelined
+const size_t PIPE_CHUNK_RAYS = (size_t)1 << 15; // rays per piece when a batch is pipelined
 
 } // namespace
 
@@ -530,7 +566,7 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 	}
 	rtk_dev_scene *ds = resident(scene);
 	if (!ds) return (size_t)-1;
-	if (n < 2 * PIPE_CHUNK) {
+	if (n < 2 * PIPE_CHUNK_RAYS) {
 		HostCtx &c = t_ctx;
 		if (!c.ensure(n)) return (size_t)-1;
 		static const int one_default = getenv("RTK_AMD_ONE_RAY_KERNEL") ? atoi(getenv("RTK_AMD_ONE_RAY_KERNEL")) : 1;
@@ -543,6 +579,25 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 	}
 	// Two staging sets on two streams: while the GPU works on one piece the host copies the previous piece's results out
 	// and the next piece's rays in (both single-threaded memcpy-speed work that used to sit between the launches).
+	// An image (recognised by its regular step, as rtk_dev_trace_rays does for device rays) goes in bands of whole 64-pixel rows, each
+	// announced to the launch as the image it is: the packet kernels instead of one ray per lane.
+	size_t PIPE_CHUNK = PIPE_CHUNK_RAYS;
+	rtk_trace_opts band_opts;
+	const rtk_trace_opts *piece_opts = nullptr;
+	{
+		uint32_t iw = 0, ih = 0;
+		static const bool detect = !(getenv("RTK_AMD_DETECT_IMAGE") && atoi(getenv("RTK_AMD_DETECT_IMAGE")) == 0);
+		if (detect) host_detect_image(rays, n, &iw, &ih);
+		if (iw >= 128u && (iw % 64u) == 0u && (ih % 64u) == 0u && (size_t)iw * 64u <= ((size_t)1 << 21)) {
+			size_t band_rows = 64;
+			while ((band_rows * 2) * (size_t)iw <= ((size_t)1 << 18) && band_rows * 2 <= ih) band_rows *= 2;
+			PIPE_CHUNK = band_rows * (size_t)iw;
+			memset(&band_opts, 0, sizeof(band_opts));
+			band_opts.struct_size = sizeof(band_opts);
+			band_opts.image_width = iw;
+			piece_opts = &band_opts;
+		}
+	}
 	HostCtx *ctx[2] = { &t_ctx, &t_ctx2 };
 	if (!ctx[0]->ensure(PIPE_CHUNK) || !ctx[1]->ensure(PIPE_CHUNK)) return (size_t)-1;
 	size_t count = 0, piece = 0;
@@ -557,7 +612,8 @@ extern "C" size_t rtk_trace_rays(const rtk_scene *scene, const rtk_ray *rays, si
 			count += r;
 		}
 		const size_t m = n - at < PIPE_CHUNK ? n - at : PIPE_CHUNK;
-		if (!enqueue_piece(ds, *ctx[k], rays + at, m, hits != nullptr, false)) { failed = true; break; }
+		if (piece_opts) band_opts.image_height = (uint32_t)(m / band_opts.image_width);      // (the last band may be lower; still whole 64-pixel rows)
+		if (!enqueue_piece(ds, *ctx[k], rays + at, m, hits != nullptr, false, piece_opts)) { failed = true; break; }
 		busy[k] = true; at_of[k] = at; n_of[k] = m;
 	}
 	// drain in submission order (the older piece first)

@@ -480,6 +480,31 @@ def test_striped_exchange_across_real_gpus(api):
         L.rtk_mgpu_destroy(m)
 
 
+def test_a_host_batch_that_is_an_image_goes_through_the_packet_kernels_in_bands(api):
+    """rtk_trace_rays (host rays in, full rtk_hit out) cuts a batch into pieces for its staging buffers; a batch it recognises as a
+    row-major image is cut into bands of whole 64-pixel rows, each announced to the launch as an image. 1024 x 704 pixels: eleven
+    rows of blocks, so the last band is lower than the others. Every hit equals what the per-ray call (served on the host, an
+    independent walk of the same blob) returns for that ray."""
+    tris = synth.triangle_soup(200_000, 0.03, seed=5)
+    scene, keep = api.build_scene([dict(positions=tris)])
+    try:
+        frame = synth.rays_pinhole(1024, 704)
+        hits, mask = api.trace_rays(scene, frame)
+        assert 0.5 < mask.mean() < 1.0
+        for i in np.random.RandomState(1).randint(0, len(frame), 3000):
+            one = api.trace_ray(scene, frame[i])
+            assert (one is not None) == bool(mask[i]), i
+            assert one is None or one.tobytes() == hits[i].tobytes(), i
+        # a batch that is no image: pieces of 32 k rays as before
+        inc = synth.rays_incoherent(100_000)
+        h2, m2 = api.trace_rays(scene, inc)
+        for i in range(0, 100_000, 97):
+            one = api.trace_ray(scene, inc[i])
+            assert (one is not None) == bool(m2[i]) and (one is None or one.tobytes() == h2[i].tobytes()), i
+    finally:
+        api.free_scene(scene)
+
+
 def test_filter_rejection_chains_longer_than_one_launch_collects(api, oracle):
     """A stack of 150 parallel triangles: a single ray collects 64 candidates per launch, a 16k-ray batch 4 per
     launch; rejecting the first 100 candidates of every ray needs several rounds and still returns candidate 101,
