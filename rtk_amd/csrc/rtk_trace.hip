@@ -1175,8 +1175,8 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	}
 	int hot_blocks_per_cu = 0;
 	const bool hot = packet && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
-		ds->bound_abs < 0x1p19f && ds->big_leaf_fraction <= 0.02 && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&
-		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu, beam);
+		ds->bound_abs < 0x1p19f && (beam >= 2 || ds->big_leaf_fraction <= 0.02) && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&
+		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu, beam);       // (rtk_packet_beam2 has the group rule for leaves of four and more triangles; the one-tile kernels hand such tiles back)
 	if (pk_counted && !hot) { rtk_set_error("rtk_dev_trace_rays_packet_counted: this batch does not run on the assembly packet kernel (image hint, whole 64x64-pixel blocks, small leaves)"); return RTK_AMD_ERR_UNSUPPORTED; }
 	static const bool path_log = getenv("RTK_AMD_LOG_PATH") != nullptr;
 	if (path_log) fprintf(stderr, "rtk_dev_trace: n %zu image %u x %u packet %d hot %d beam %d opts %p flags %x\n", n, p.image_w, p.image_h, (int)packet, (int)hot, beam, (const void *)opts, opts ? opts->flags : 0u);
@@ -1189,7 +1189,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	int lane_blocks_per_cu = 0;
 	const bool lane_hot = !packet && !collect && !counted && !filtered && qn && p.dynamic && p.image_w == 0 && lane_asm_default != 0 &&
 		RTK_TRI_STRIDE == 48 && n <= ((size_t)1 << 26) && (uint64_t)ds->view.num_nodes * 64u < 0x80000000ull &&
-		(uint64_t)ds->view.num_tris * RTK_TRI_STRIDE < 0x80000000ull && ds->bound_abs < 0x1p60f && ds->big_leaf_fraction <= 0.02 &&
+		(uint64_t)ds->view.num_tris * RTK_TRI_STRIDE < 0x80000000ull && ds->bound_abs < 0x1p60f && (!any_hit || ds->big_leaf_fraction <= 0.02) &&
 		!(opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_NO_ASM | RTK_TRACE_STATIC))) && ds->stack_entries < 512u &&
 		rtk_lane_hot_available(ds->device, &lane_blocks_per_cu);
 

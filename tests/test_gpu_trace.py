@@ -309,3 +309,28 @@ def test_an_image_is_recognised_without_the_hint(api, scene1):
     # check is indirect: the per-lane kernel and the packet kernel agree, and a batch that is no image is untouched by the look)
     inc = synth.rays_incoherent(32768)
     assert ds.trace(inc, full=False).tobytes() == ds.trace(inc, opts=api.make_opts(no_detect=True), full=False).tobytes()
+
+
+def test_the_references_leaf_sizes_stay_on_the_hand_written_kernels(api, oracle, scene2):
+    """The oracle's SAH builder makes leaves of 4 to 63 triangles like the reference's (rtk.c:6-7). Their full groups of four take the
+    float edge functions in rtk_packet_beam2 and rtk_lane_hot_closest (the padded last group double precision), so such scenes --
+    every imported blob, every rtk_cpu_build.cpp scene -- are not handed to the C++ kernels any more: no tile of a 1024 x 1024 frame
+    comes back, and frame and incoherent rays are the oracle's answers bit for bit on the same leaves."""
+    blob, ds = scene2
+    assert ds.info()["num_triangles"] == 1_000_000
+    frame = synth.rays_pinhole(1024, 1024)
+    opts = api.make_opts(image=(1024, 1024))
+    rec, pk = ds.trace_packet_counted(frame, opts)
+    assert pk["tiles"] == 16384 and pk["tiles_handed_back"] <= 16, pk         # (the tiles across the image axes have rays of both signs; an exact zero in a full group would hand a pair back too)
+    assert pk["triangle_group_tests"] > 4 * pk["pairs"]
+    sel = np.arange(0, len(frame), 7)
+    oh, om = oracle.trace(blob, np.ascontiguousarray(frame[sel]))
+    g = rec[sel]
+    assert ((g["prim"] != 0xFFFFFFFF) == om).all()
+    assert (g["t"][om] == oh["t"][om]).all() and (g["u"][om] == oh["u"][om]).all() and (g["v"][om] == oh["v"][om]).all()
+    inc = synth.rays_incoherent(1 << 18)
+    r2 = ds.trace(inc, full=False)
+    oh, om = oracle.trace(blob, inc)
+    assert ((r2["prim"] != 0xFFFFFFFF) == om).all()
+    assert (r2["t"][om] == oh["t"][om]).all() and (r2["u"][om] == oh["u"][om]).all() and (r2["v"][om] == oh["v"][om]).all()
+    assert r2.tobytes() == ds.trace(inc, opts=api.make_opts(no_asm=True), full=False).tobytes()

@@ -200,6 +200,19 @@ def chain_oracle(oracle, tv, rays):
     return oracle.trace_chain(blobs, rays, threads=4)
 
 
+def leaf_oracle(oracle, tr, rays):
+    """rtk.c's arithmetic with the LEAVES of the device records as its groups: one single-leaf blob per leaf, its triangles in the
+    records' order -- full groups of four (float edge functions, all four redone in double on an exact zero, rtk.c:302-336) and a
+    padded last group, exactly what the kernels must reproduce for leaves of four or more triangles."""
+    starts = np.nonzero(tr["count"] > 0)[0]
+    blobs = []
+    for s0 in starts:
+        c = int(tr["count"][s0])
+        tv = np.stack([tr["v0"][s0:s0 + c], tr["v1"][s0:s0 + c], tr["v2"][s0:s0 + c]], axis=1)
+        blobs += oracle.leaf_chain_blobs(tv, triangle_index=tr["prim"][s0:s0 + c], chunk=64)
+    return oracle.trace_chain(blobs, rays, threads=4)
+
+
 @pytest.fixture(scope="module")
 def oracle():
     from oracle import pyoracle
@@ -270,21 +283,30 @@ def test_launch_parameters_do_not_change_results(lane_obj, oracle, soup):
         assert len(left) == 0 and res.tobytes() == ref.tobytes()
 
 
-def test_untame_rays_and_big_leaves_are_handed_back(lane_obj, oracle):
+def test_untame_rays_are_handed_back_and_big_leaves_follow_the_group_rule(lane_obj, oracle):
+    """Leaves of four to nine triangles: the closest-hit kernel computes the edge functions of their FULL groups in float (rtk.c:298-300)
+    and those of the padded last group in double, bit for bit the reference on the same leaves; a ray that meets an exact zero in a
+    full group (the group would be redone in double) is handed back, as are untame rays. The any-hit kernel still hands every ray
+    back that meets such a leaf."""
     tv = synth.triangle_soup(200, 0.2, seed=3).reshape(-1, 3, 3)
-    qn, tr = build_bvh4(tv, leaf_max=5)                # some leaves of four and five triangles
-    assert (tr["count"] > 3).any()
+    qn, tr = build_bvh4(tv, leaf_max=13)               # leaves of up to thirteen triangles: full groups and a padded one
+    assert (tr["count"] > 3).any() and (tr["count"] > 7).any()
     rays = some_rays(256, 5)
     ex = synth.rays_exotic(64, seed=9, tris=tv)
     rays[::4] = ex[:64]
-    g_hits, g_mask = chain_oracle(oracle, tv, rays)
+    g_hits, g_mask = leaf_oracle(oracle, tr, rays)
     res, left, _ = run_lane_kernel(lane_obj, False, qn, tr, rays)
     done = check_closest(res, left, g_hits, g_mask, rays)
     assert 0 < done.sum() < len(rays)
     d, o = rays["direction"], rays["origin"]
     untame = (d == 0).any(axis=1) | ~np.isfinite(d).all(axis=1) | ~np.isfinite(o).all(axis=1) | np.isnan(rays["min_t"]) | np.isnan(rays["max_t"])
     assert not done[untame].any()
+    assert done[~untame].mean() > 0.85                 # (big leaves are no reason to hand a ray back any more; exotic rays outside 2^+-60 and exact zeros still are)
     assert len(np.unique(left)) == len(left)
+    # the grouping matters: the same rays against one-triangle groups (double precision throughout) differ in some low bits
+    f_hits, f_mask = chain_oracle(oracle, tv, rays)
+    both = g_mask & f_mask & done
+    assert (g_hits["t"][both].view(np.uint32) != f_hits["t"][both].view(np.uint32)).any()
     res_a, left_a, _ = run_lane_kernel(lane_obj, True, qn, tr, rays)
     done_a = np.ones(len(rays), bool)
     done_a[(left_a & np.uint64(0xffffffff)).astype(np.int64)] = False

@@ -317,3 +317,27 @@ def test_the_other_two_dominant_axes(oracle, shift):
     for obj in ("rtk_packet_beam2", "rtk_packet_beam"):
         res, left, _ = run_packet_kernel(obj, nodes, tr, rays, W, H, workgroups=1)
         assert len(left) == 0 and check(res, left, g_hits, g_mask, rays, W, H).all()
+
+
+def test_leaves_of_four_and_more_triangles_follow_the_group_rule(oracle):
+    """The reference's own builder makes leaves of 4 to 64 triangles (rtk.c:6-7); their first count & ~3 triangles form FULL groups of
+    four -- float edge functions, rtk.c:298-300 -- and only the padded last group is computed in double. rtk_packet_beam2 does that
+    (bit for bit the reference on the same leaves: the oracle walks one single-leaf blob per leaf); a pair that meets an exact zero
+    in a full group is handed back. The one-tile kernels still hand every tile back that meets such a leaf."""
+    from .test_lane_asm_emulated import leaf_oracle
+    subprocess.check_call(["make", "-s", "-C", CSRC, os.path.join(os.path.abspath(CSRC), "obj", "rtk_packet_hot.hsaco")])
+    tv = synth.triangle_soup(500, 0.15, seed=11).reshape(-1, 3, 3)
+    qn, tr, nodes = build_bvh4(tv, leaf_max=13, want_exact=True)
+    assert (tr["count"] > 7).any()
+    rays = camera(0.02, 0.05, 0.55)
+    g_hits, g_mask = leaf_oracle(oracle, tr, rays)
+    res, left, _ = run_packet_kernel("rtk_packet_beam2", nodes, tr, rays, W, H, workgroups=1)
+    done = check(res, left, g_hits, g_mask, rays, W, H)
+    assert done.mean() > 0.9 and 0.2 < g_mask.mean() < 0.98
+    # the grouping matters: against one-triangle groups (double precision throughout) some low bits differ
+    f_hits, f_mask = chain_oracle(oracle, tv, rays)
+    both = g_mask & f_mask & done
+    assert (g_hits["t"][both].view(np.uint32) != f_hits["t"][both].view(np.uint32)).any()
+    res1, left1, _ = run_packet_kernel("rtk_packet_beam", nodes, tr, rays, W, H, workgroups=1)
+    done1 = check(res1, left1, g_hits, g_mask, rays, W, H)
+    assert done1.mean() < done.mean()
