@@ -1045,16 +1045,14 @@ int rtk_detect_image(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	rtk_dev_scene *ds = const_cast<rtk_dev_scene *>(ds_c);
 	*w_out = *h_out = 0u;
 	if (!ds || !d_rays || n < 4u || n > 0x40000000ull) return RTK_AMD_OK;
-	uint32_t *d_word = nullptr;
-	volatile uint32_t *h_verdict = nullptr;
-	{
-		std::lock_guard<std::mutex> lock(ds->scratch_mutex);
-		LaunchScratch *sc0 = scratch_for(ds, stream);
-		if (!sc0) return RTK_AMD_ERR_OOM;
-		d_word = reinterpret_cast<uint32_t *>(sc0->d_counter + RTK_DETECT_WORD);
-		if (!sc0->h_verdict) RTK_HIP_CHECK(hipHostMalloc((void **)&sc0->h_verdict, 64, hipHostMallocDefault), RTK_AMD_ERR_OOM);     // (pinned: the kernel writes the verdict there)
-		h_verdict = sc0->h_verdict;
-	}
+	// (the look uses two words of the (scene, stream) scratch set and its pinned verdict: the scene's scratch mutex is held until the
+	// verdict has been read, so that two host threads feeding one stream cannot interleave their looks; ~30 us)
+	std::lock_guard<std::mutex> lock(ds->scratch_mutex);
+	LaunchScratch *sc0 = scratch_for(ds, stream);
+	if (!sc0) return RTK_AMD_ERR_OOM;
+	uint32_t *d_word = reinterpret_cast<uint32_t *>(sc0->d_counter + RTK_DETECT_WORD);
+	if (!sc0->h_verdict) RTK_HIP_CHECK(hipHostMalloc((void **)&sc0->h_verdict, 64, hipHostMallocDefault), RTK_AMD_ERR_OOM);     // (pinned: the kernel writes the verdict there)
+	volatile uint32_t *h_verdict = sc0->h_verdict;
 	const uint32_t limit = (uint32_t)std::min<size_t>(n, (size_t)1 << 17);
 	RTK_HIP_CHECK(hipMemsetAsync(d_word, 0xff, 4, stream), RTK_AMD_ERR_HIP);
 	hipLaunchKernelGGL(k_detect_row, dim3((limit + 255u) / 256u), dim3(256), 0, stream, d_rays, limit, d_word);
