@@ -143,6 +143,7 @@ bool Walker::leaf(uint64_t ptr)
 			const float t = ts[l];
 			const BlobTri *tri = &tris[g + l];
 			if (!(t <= best_t)) continue;                                   // cheap reject before the id is looked up
+			if (at + 8 + slots * 8 + 4 * ((uint64_t)tri->local_mesh + 1) > size) return false;     // (the leaf-local mesh table ends inside the blob)
 			const uint32_t mesh = mesh_table[tri->local_mesh];
 			if (t == best_t && !(found && id_before(mesh, tri->triangle_index, best_mesh, best_tri->triangle_index))) continue;
 			if (has_after && !(t > after_t || (t == after_t && id_before(after_mesh, after_tri, mesh, tri->triangle_index)))) continue;
