@@ -1292,7 +1292,41 @@ __global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const 
 	}
 }
 
-__global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, int n, const int2 *lr, const uint2 *range, const BinNode *bin, const float *area,
+// Transposes the W x W matrix of 16-byte pieces that W neighbouring lanes hold (lane i of the group: pieces p[0 .. W) of ITS
+// record) so that lane i ends up with piece i of each of the W records: p[k] = piece i of the record of lane k of the group.
+// A store of p[k] then writes the whole record of lane k from W neighbouring lanes -- W * 16 contiguous bytes -- instead of one
+// 16-byte piece per lane at the stride of the records (64 partial lines per instruction). All lanes of the wave take part.
+template <int W>
+__device__ __forceinline__ void transpose_pieces(uint4 (&p)[W])
+{
+	const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+	for (int s = 1; s < W; s <<= 1) {
+		const bool up = (lane & (uint32_t)s) != 0u;
+#pragma unroll
+		for (int h = 0; h < W / 2; h++) {
+			const int a = ((h & ~(s - 1)) << 1) | (h & (s - 1));       // the h-th piece number without bit s
+			// (values first, then the select: `up ? p[a] : p[b]` selects between two ADDRESSES, and the array lands in scratch memory)
+			uint4 &lo_p = p[a], &hi_p = p[a ^ s];
+#define SWAP_PIECE(c_) { const uint32_t l_ = lo_p.c_, h_ = hi_p.c_; const uint32_t send = up ? l_ : h_; const uint32_t recv = (uint32_t)__shfl_xor((int)send, s); lo_p.c_ = up ? recv : l_; hi_p.c_ = up ? h_ : recv; }
+			SWAP_PIECE(x) SWAP_PIECE(y) SWAP_PIECE(z) SWAP_PIECE(w)
+#undef SWAP_PIECE
+		}
+	}
+}
+
+#ifdef RTK_TILE_PHASES
+__device__ unsigned long long g_tile_phase[8];
+#define PHASE_MARK(i_) do { if (threadIdx.x == 0) ph[i_] = wall_clock64(); } while (0)
+#else
+#define PHASE_MARK(i_)
+#endif
+#ifdef RTK_TILE_WAVES
+#define TILE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RTK_TILE_WAVES, RTK_TILE_WAVES)))
+#else
+#define TILE_WAVES_ATTR
+#endif
+__global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(DevTri *tris, int n, const int2 *lr, const uint2 *range, const BinNode *bin, const float *area,
 	const Climb *climbers, const int *climb_idx, const uint32_t *tile_nclimb, const unsigned long long *tile_parent, const uint32_t *tile_base, uint32_t node_offset,
 	DevNode *nodes, DevNodeQ *qnodes, uint32_t node_cap, DevSceneConsts *consts, uint32_t *depth_word)
 {
@@ -1307,9 +1341,14 @@ __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, in
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
 	const int t = (int)threadIdx.x;
+#ifdef RTK_TILE_PHASES
+	unsigned long long ph[6];
+#endif
+	PHASE_MARK(0);
 	tile_load<TILE_THREADS>(lo, hi, lr, range, area, climbers, climb_idx, tile_nclimb[blockIdx.x], s_lr, s_area, s_start, s_roots, &s_nroots);
 	for (int k = t; k < REFIT_TILE; k += TILE_THREADS) s_base[k] = 0u;
 	__syncthreads();
+	PHASE_MARK(1);
 	if (t < 64) {
 		const uint32_t cnt = tile_bfs(lo, s_lr, s_area, s_start, s_roots, s_nroots, tile_parent, s_round, s_spine, s_lvl, reinterpret_cast<uint32_t *>(s_base));
 		// pre-order numbers: jobs that start further left (prefix sums over the per-start counters, 16 per lane) + jobs above
@@ -1326,6 +1365,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, in
 		if (t == 0) s_count = cnt;
 	}
 	__syncthreads();
+	PHASE_MARK(2);
 	const uint32_t count = s_count;
 	const uint32_t base = node_offset + tile_base[blockIdx.x];
 #define TILE_LOCAL(k_) ((uint32_t)s_base[s_start[k_]] + (uint32_t)s_spine[k_])
@@ -1338,10 +1378,13 @@ __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, in
 	// number -> binary node (s_map), then the nodes themselves, dense: thread j makes wide nodes j, j + blockDim, ... of the tile
 	for (uint32_t j = (uint32_t)t; j < count; j += TILE_THREADS) { const uint32_t k = s_round[j]; s_map[TILE_LOCAL(k)] = (uint16_t)k; }
 	__syncthreads();
+	PHASE_MARK(3);
 	bool misfit = false;
 	uint32_t deepest = 0;
-	for (uint32_t j = (uint32_t)t; j < count; j += TILE_THREADS) {
-		const int bk = (int)s_map[j];
+	// (every lane of a wave goes through the loop as long as one of them has a node to make: the stores below are shared)
+	for (uint32_t j = (uint32_t)t; (j & ~63u) < count; j += TILE_THREADS) {
+		const bool made = j < count;
+		const int bk = made ? (int)s_map[j] : (int)s_map[0];
 		int ch4[4];
 		const int nc = tile_open(lo + bk, lo, s_lr, s_area, ch4);
 		DevNode nd;
@@ -1375,7 +1418,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, in
 				if (s_area[ch4[k] - lo] > 0.0f) ref = base + TILE_LOCAL(ch4[k] - lo);
 				else {
 					const uint2 lf = range[ch4[k]];                                // a subtree the SAH rule turned into one leaf
-					mark_leaf(tris, lf);
+					if (made) mark_leaf(tris, lf);
 					ref = RTK_REF_LEAF | lf.x;
 				}
 			}
@@ -1386,18 +1429,52 @@ __global__ void __launch_bounds__(TILE_THREADS) k_collapse_tile(DevTri *tris, in
 		}
 		child_order(nd, nd.order);
 		DevNodeQ q;
-		if (!quantize_node(nd, q)) misfit = true;
+		if (!quantize_node(nd, q) && made) misfit = true;
 		// (a tree with more nodes than the scene's arrays were sized for drops the writes beyond them; the host repeats)
-		if (base + j < node_cap) {
-			nodes[base + j] = nd;
-			qnodes[base + j] = q;
+		// the stores: eight neighbouring lanes write one node (its eight 16-byte rows), four its compressed copy
+		{
+			uint4 p[8], pq[4];
+#define ROW_F(a_) make_uint4(__float_as_uint((a_)[0]), __float_as_uint((a_)[1]), __float_as_uint((a_)[2]), __float_as_uint((a_)[3]))
+#define ROW_U(a_) make_uint4((a_)[0], (a_)[1], (a_)[2], (a_)[3])
+			p[0] = ROW_F(nd.bx[0]); p[1] = ROW_F(nd.bx[1]); p[2] = ROW_F(nd.by[0]); p[3] = ROW_F(nd.by[1]);
+			p[4] = ROW_F(nd.bz[0]); p[5] = ROW_F(nd.bz[1]); p[6] = ROW_U(nd.child); p[7] = ROW_U(nd.order);
+			pq[0] = make_uint4(__float_as_uint(q.org[0]), __float_as_uint(q.org[1]), __float_as_uint(q.org[2]), __float_as_uint(q.scale[0]));
+			pq[1] = make_uint4(__float_as_uint(q.scale[1]), __float_as_uint(q.scale[2]), q.q[0][0], q.q[0][1]);
+			pq[2] = make_uint4(q.q[1][0], q.q[1][1], q.q[2][0], q.q[2][1]);
+			pq[3] = ROW_U(q.child);
+#undef ROW_F
+#undef ROW_U
+			transpose_pieces<8>(p);
+			transpose_pieces<4>(pq);
+			const uint32_t lane = (uint32_t)t & 63u, j0 = j - lane;
+#pragma unroll
+			for (uint32_t k = 0; k < 8u; k++) {
+				const uint32_t jn = j0 + (lane & ~7u) + k;                                           // the node of lane k of this group of eight
+				if (jn < count && base + jn < node_cap) reinterpret_cast<uint4 *>(nodes + base + jn)[lane & 7u] = p[k];
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 4u; k++) {
+				const uint32_t jn = j0 + (lane & ~3u) + k;
+				if (jn < count && base + jn < node_cap) reinterpret_cast<uint4 *>(qnodes + base + jn)[lane & 3u] = pq[k];
+			}
 		}
-		deepest = deepest > (uint32_t)s_lvl[bk] + 1u ? deepest : (uint32_t)s_lvl[bk] + 1u;      // (the scene's depth counts levels from 1)
+		if (made) deepest = deepest > (uint32_t)s_lvl[bk] + 1u ? deepest : (uint32_t)s_lvl[bk] + 1u;      // (the scene's depth counts levels from 1)
 	}
 #undef TILE_LOCAL
 	if (misfit) atomicAdd(&consts->qnode_misfits, 1u);
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(deepest, o); deepest = deepest > u ? deepest : u; }
 	if ((t & 63) == 0 && deepest) atomicMax(depth_word, deepest);
+#ifdef RTK_TILE_PHASES
+	__syncthreads();
+	PHASE_MARK(4);
+	if (threadIdx.x == 0) {
+		for (int i = 0; i < 4; i++) atomicAdd(&g_tile_phase[i], ph[i + 1] - ph[i]);
+		atomicAdd(&g_tile_phase[4], 1ull);
+		atomicAdd(&g_tile_phase[5], (unsigned long long)count);
+		atomicMax(&g_tile_phase[6], ((ph[4] - ph[0]) << 32) | blockIdx.x);
+		atomicMax(&g_tile_phase[7], ((ph[4] - ph[3]) << 32) | count);
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -2073,6 +2150,16 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 				hipMemcpyAsync(&h_tail[1], d_depth_word, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipStreamSynchronize(bs) != hipSuccess) return fail("tile collapse");
+#ifdef RTK_TILE_PHASES
+			{
+				unsigned long long h[8] = {}, z[8] = {};
+				(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tile_phase), sizeof(h));
+				(void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_phase), z, sizeof(z));
+				if (h[4]) fprintf(stderr, "rtk_amd tile phases (10 ns ticks per tile): load %.0f bfs %.0f number %.0f finish %.0f; tiles %llu jobs/tile %.0f\n",
+					(double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4], h[4], (double)h[5] / h[4]);
+				fprintf(stderr, "rtk_amd tile phases: slowest tile %llu ticks (tile %llu); slowest finish %llu ticks (%llu jobs)\n", h[6] >> 32, h[6] & 0xffffffffull, h[7] >> 32, h[7] & 0xffffffffull);
+			}
+#endif
 			if (timing) {
 				std::vector<uint32_t> hc(num_tiles + 1), hb(num_tiles + 1);
 				(void)hipMemcpy(hc.data(), d_tile_count, (num_tiles) * 4, hipMemcpyDeviceToHost);
