@@ -450,8 +450,9 @@ struct MeshSrc { const char *pos; unsigned long long stride; };
 __global__ void k_emit_tris(const InTri *in_tris, const MeshSrc *src, const uint32_t *vals, const unsigned long long *words, uint32_t n,
 	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris)
 {
-	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= n) return;
+	const uint32_t s_own = blockIdx.x * blockDim.x + threadIdx.x;
+	if ((s_own & ~63u) >= n) return;                                            // (whole waves only: the stores below are shared by the wave)
+	const uint32_t s = s_own < n ? s_own : n - 1u;                              // (lanes behind the last triangle make a copy of it that is not written)
 	const uint32_t g = vals ? vals[s] : (uint32_t)(words[s] & 0xffffffull);     // packed sort words carry the index in their low 24 bits
 	// mesh of global primitive g: last m with mesh_base[m] <= g
 	uint32_t lo = 0, hi = num_meshes;
@@ -480,8 +481,42 @@ __global__ void k_emit_tris(const InTri *in_tris, const MeshSrc *src, const uint
 	t.spare = 1u;
 #if RTK_TRI_STRIDE == 64
 	t.pad[0] = t.pad[1] = t.pad[2] = t.pad[3] = 0u;
+	if (s_own < n) tris[s] = t;
+#else
+	// The wave's 64 records are 192 16-byte pieces in a row: store k writes pieces 64 k + lane, 1 KB without a gap (a record per
+	// lane is three stores of 16 bytes at a stride of 48: 64 partial lines each). Piece w of the record of lane r is number
+	// 3 r + w: it goes to lane (3 r + w) mod 64 -- one to one, 3 and 64 have no common factor -- which receives one piece for
+	// each of its three stores: the one of store k has w = (lane + k) mod 3 (64 = 1 mod 3).
+	{
+		const uint32_t lane = threadIdx.x & 63u;
+		const uint32_t piece[3][4] = {
+			{ __float_as_uint(t.v0[0]), __float_as_uint(t.v0[1]), __float_as_uint(t.v0[2]), t.prim },
+			{ __float_as_uint(t.v1[0]), __float_as_uint(t.v1[1]), __float_as_uint(t.v1[2]), t.flags },
+			{ __float_as_uint(t.v2[0]), __float_as_uint(t.v2[1]), __float_as_uint(t.v2[2]), t.spare } };
+		uint32_t got[3][4];
+#pragma unroll
+		for (uint32_t w = 0; w < 3u; w++) {
+			const int to = (int)(((3u * lane + w) & 63u) << 2);
+#pragma unroll
+			for (int c = 0; c < 4; c++) got[w][c] = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)piece[w][c]);
+		}
+		uint4 *out = reinterpret_cast<uint4 *>(tris + (s_own - lane));
+		const uint32_t left = n - (s_own - lane);                               // records of this wave that exist
+		const uint32_t w0 = lane % 3u;
+#pragma unroll
+		for (uint32_t k = 0; k < 3u; k++) {
+			const uint32_t w = (w0 + k) % 3u, m = 64u * k + lane;
+			uint4 v;
+			const uint32_t a0 = got[0][0], a1 = got[1][0], a2 = got[2][0], b0 = got[0][1], b1 = got[1][1], b2 = got[2][1];
+			const uint32_t c0 = got[0][2], c1 = got[1][2], c2 = got[2][2], d0 = got[0][3], d1 = got[1][3], d2 = got[2][3];
+			v.x = w == 0u ? a0 : (w == 1u ? a1 : a2);
+			v.y = w == 0u ? b0 : (w == 1u ? b1 : b2);
+			v.z = w == 0u ? c0 : (w == 1u ? c1 : c2);
+			v.w = w == 0u ? d0 : (w == 1u ? d1 : d2);
+			if (m / 3u < left) out[m] = v;
+		}
+	}
 #endif
-	tris[s] = t;
 	// (the side arrays -- original vertex indices, primitive -> slot, slot -> mesh / triangle -- were written here, 52 bytes per
 	// triangle with one scattered word: rtk_scene_side_arrays makes them when something asks for a full rtk_hit, a validation or
 	// an export, not in every build)
@@ -712,8 +747,15 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	}
 	__syncthreads();
 	if (t == 0) tile_nclimb[blockIdx.x] = s_nclimb;
+	// the finished records, 16 bytes per thread and store in the order they lie in LDS and in memory (a 32-byte record per
+	// thread is two stores of half lines at a stride of 32)
+	static_assert(sizeof(BinNode) == 32 && REFIT_BLOCK == REFIT_TILE, "two 16-byte pieces per record, one record per thread");
+#pragma unroll
+	for (int m = t; m < 2 * REFIT_TILE; m += REFIT_BLOCK) {
+		const int rec = m >> 1;
+		if (lo + rec < hi && s_arrive[rec] == 2u) reinterpret_cast<uint4 *>(bin + lo)[m] = reinterpret_cast<const uint4 *>(s_bin)[m];
+	}
 	if (i < hi && s_arrive[t] == 2u) {
-		bin[i] = s_bin[t];
 		if (area) area[i] = open_area(s_bin[t]);      // what the tile-local collapse ranks children by (4 bytes instead of the 32-byte record)
 		lr[i] = s_lr[t];
 		range[i] = make_uint2((uint32_t)s_rl[t], (uint32_t)s_rr[t]);
