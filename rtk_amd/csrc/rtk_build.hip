@@ -938,12 +938,16 @@ __device__ __forceinline__ void mark_leaf(DevTri *tris, const uint2 rg)
 
 // Opens binary node b as wide node `node_index`: chooses its (up to four) children and writes the node except for the
 // numbers of the children that are wide nodes themselves. Returns how many those are.
-// tile_parent != NULL: tile mode. Children that are tile jobs keep an empty child word for now; where that word is (node,
-// slot) and the level of this node go to tile_parent[child], for k_collapse_tile to fill in.
+// aux.tile_refs != NULL: tile mode -- the nodes ABOVE the refit tiles, written to a stretch of the workspace with numbers of
+// their own (k_top_finish moves them behind the tiles' nodes, which k_collapse_tile makes at the same time on another stream).
+// Children that are tile jobs keep an empty child word; WHICH binary node hangs in the slot goes to aux.tile_refs[node]
+// (+ 1; 0: not a tile job) and the node's level to aux.level[node], for k_top_finish.
+struct TopAux { uint4 *tile_refs; uint32_t *level; };
 __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, const int2 *lr, const uint2 *range, const BinNode *bin,
-	DevTri *tris, DevNode *nodes, uint32_t node_cap, int4 &dec, uint32_t &info, unsigned long long *tile_parent = nullptr, uint32_t level = 0)
+	DevTri *tris, DevNode *nodes, uint32_t node_cap, int4 &dec, uint32_t &info, TopAux aux = TopAux{ nullptr, nullptr }, uint32_t level = 0)
 {
-	const bool tile_mode = tile_parent != nullptr;
+	const bool tile_mode = aux.tile_refs != nullptr;
+	uint32_t tref[4] = { 0u, 0u, 0u, 0u };
 	Cand c[4];
 	int nc;
 	const BinNode self = bin[b];
@@ -1000,8 +1004,9 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 			n_inner++;
 			r[k] = ref;                                           // binary reference; becomes a node number when this level is numbered
 		} else if (c[k].tile_job) {
-			r[k] = (int)RTK_REF_NONE;                             // k_collapse_tile writes the number of the wide node it makes of it
-			tile_parent[ref] = ((unsigned long long)level << 34) | ((unsigned long long)node_index << 2) | (unsigned long long)k;
+			r[k] = (int)RTK_REF_NONE;                             // k_top_finish writes the number of the wide node k_collapse_tile makes of it
+#pragma unroll
+			for (int q = 0; q < 4; q++) if (q == k) tref[q] = (uint32_t)ref + 1u;
 		} else {
 			const uint2 rg = range[ref];
 			mark_leaf(tris, rg);
@@ -1019,6 +1024,10 @@ __device__ __forceinline__ uint32_t collapse_open(int b, uint32_t node_index, co
 		float4 *dst = reinterpret_cast<float4 *>(nodes + node_index);
 #pragma unroll
 		for (int q = 0; q < 6; q++) dst[q] = rows[q];
+		if (tile_mode) {
+			aux.tile_refs[node_index] = make_uint4(tref[0], tref[1], tref[2], tref[3]);
+			aux.level[node_index] = level;
+		}
 	}
 	for (int k = nc; k < 4; k++) r[k] = (int)RTK_REF_NONE;
 	dec = make_int4(r[0], r[1], r[2], r[3]);                      // final child words, except the slots in `mask`: binary references
@@ -1058,7 +1067,7 @@ __device__ __forceinline__ LevelState next_level(const LevelState &L, uint32_t n
 }
 
 __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B, const LevelState *ring, uint32_t step, const int2 *lr, const uint2 *range,
-	const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, unsigned long long *tile_parent)
+	const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, TopAux aux)
 {
 	__shared__ uint32_t s_w[COLLAPSE_BLOCK / 64];
 	const LevelState L = ring[step % COLLAPSE_RING];
@@ -1069,7 +1078,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_open(CollapseBufs B
 		if (j < count) {
 			int4 d;
 			uint32_t inf;
-			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, node_cap, d, inf, tile_parent, L.level);
+			n_inner = collapse_open(B.jobs[j], L.base + j, lr, range, bin, tris, nodes, node_cap, d, inf, aux, L.level);
 			B.dec[j] = d;
 			B.info[j] = inf;
 		}
@@ -1136,7 +1145,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs
 // that is already opened (dec/info valid) and hands over one that is opened too, block sums included. Launch 0 of a
 // build opens the root first.
 __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs B, LevelState *ring, uint32_t step, uint32_t max_levels,
-	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root, unsigned long long *tile_parent)
+	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root, TopAux aux)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
 	__shared__ int s_ref[COLLAPSE_SMALL * 4];
@@ -1148,7 +1157,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		if (threadIdx.x == 0) {
 			int4 d;
 			uint32_t inf;
-			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, node_cap, d, inf, tile_parent, 0u);
+			B.sums[0] = collapse_open(*root, 0u, lr, range, bin, tris, nodes, node_cap, d, inf, aux, 0u);
 			B.dec[0] = d;
 			B.info[0] = inf;
 		}
@@ -1176,7 +1185,7 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		for (uint32_t i = threadIdx.x; i < total; i += COLLAPSE_SMALL) {
 			int4 d2;
 			uint32_t inf2;
-			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, node_cap, d2, inf2, tile_parent, N.level);
+			const uint32_t n2 = collapse_open(s_ref[i], N.base + i, lr, range, bin, tris, nodes, node_cap, d2, inf2, aux, N.level);
 			B.dec[i] = d2;
 			B.info[i] = inf2;
 			if (n2) atomicAdd(&s_sums[i / COLLAPSE_BLOCK], n2);
@@ -1272,9 +1281,11 @@ __device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const 
 //   s_spine / s_lvl / s_cnt may be NULL (counting only). s_spine[k]: how many jobs above node lo + k share its range start;
 //   s_cnt (packed 16-bit counters): jobs per range start; with these two the caller numbers the jobs in the PRE-ORDER of
 //   the forest (range start ascending, larger range first): every node after its parent, subtrees contiguous, numbers that
-//   depend on the tree alone. s_lvl[k]: level of the node in the whole tree (roots: level of the node above + 1, tile_parent).
+//   depend on the tree alone. s_lvl[k]: level of the node below its tile root (the root: 0); s_rootof[k]: which root that is
+//   (its place in s_roots); s_rdepth[r]: the deepest level below root r -- where a root hangs in the tree is not known
+//   here (the nodes above the tiles are collapsed at the same time, on another stream): k_top_finish adds the two.
 __device__ __forceinline__ uint32_t tile_bfs(int lo, const int2 *s_lr, const float *s_area, const uint16_t *s_start, const int *s_roots, uint32_t nroots,
-	const unsigned long long *tile_parent, uint16_t *s_q, uint16_t *s_spine, uint8_t *s_lvl, uint32_t *s_cnt)
+	uint16_t *s_q, uint16_t *s_spine, uint8_t *s_lvl, uint32_t *s_cnt, uint16_t *s_rootof, uint32_t *s_rdepth)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	for (uint32_t r = lane; r < nroots; r += 64u) {
@@ -1282,8 +1293,9 @@ __device__ __forceinline__ uint32_t tile_bfs(int lo, const int2 *s_lr, const flo
 		s_q[r] = (uint16_t)k;
 		if (s_spine) {
 			s_spine[k] = 0u;
-			const uint32_t l = (uint32_t)(tile_parent[s_roots[r]] >> 34) + 1u;
-			s_lvl[k] = (uint8_t)(l < 255u ? l : 255u);
+			s_lvl[k] = 0u;
+			s_rootof[k] = (uint16_t)r;
+			s_rdepth[r] = 0u;
 			atomicAdd(s_cnt + ((uint32_t)s_start[k] >> 1), (s_start[k] & 1u) ? 0x10000u : 1u);
 		}
 	}
@@ -1304,7 +1316,10 @@ __device__ __forceinline__ uint32_t tile_bfs(int lo, const int2 *s_lr, const flo
 					s_q[pos] = (uint16_t)ck;
 					if (s_spine) {
 						s_spine[ck] = s_start[ck] == s_start[t] ? (uint16_t)(s_spine[t] + 1u) : (uint16_t)0u;
-						s_lvl[ck] = (uint8_t)(s_lvl[t] < 255u ? s_lvl[t] + 1u : 255u);
+						const uint32_t l = s_lvl[t] < 255u ? s_lvl[t] + 1u : 255u;
+						s_lvl[ck] = (uint8_t)l;
+						s_rootof[ck] = s_rootof[t];
+						atomicMax(s_rdepth + s_rootof[t], l);
 						atomicAdd(s_cnt + ((uint32_t)s_start[ck] >> 1), (s_start[ck] & 1u) ? 0x10000u : 1u);
 					}
 				}
@@ -1329,7 +1344,7 @@ __global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const 
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
 	tile_load<64>(lo, hi, lr, range, area, climbers, climb_idx, tile_nclimb[blockIdx.x], s_lr, s_area, nullptr, s_roots, &s_nroots);
 	if (threadIdx.x < 64u) {
-		const uint32_t count = tile_bfs(lo, s_lr, s_area, nullptr, s_roots, s_nroots, nullptr, s_q, nullptr, nullptr, nullptr);
+		const uint32_t count = tile_bfs(lo, s_lr, s_area, nullptr, s_roots, s_nroots, s_q, nullptr, nullptr, nullptr, nullptr, nullptr);
 		if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
 	}
 }
@@ -1369,8 +1384,8 @@ __device__ unsigned long long g_tile_phase[8];
 #define TILE_WAVES_ATTR
 #endif
 __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(DevTri *tris, int n, const int2 *lr, const uint2 *range, const BinNode *bin, const float *area,
-	const Climb *climbers, const int *climb_idx, const uint32_t *tile_nclimb, const unsigned long long *tile_parent, const uint32_t *tile_base, uint32_t node_offset,
-	DevNode *nodes, DevNodeQ *qnodes, uint32_t node_cap, DevSceneConsts *consts, uint32_t *depth_word)
+	const Climb *climbers, const int *climb_idx, const uint32_t *tile_nclimb, unsigned long long *root_info, const uint32_t *tile_base, uint32_t node_offset,
+	DevNode *nodes, DevNodeQ *qnodes, uint32_t node_cap, DevSceneConsts *consts)
 {
 	__shared__ int2 s_lr[REFIT_TILE];          //  8 KB
 	__shared__ float s_area[REFIT_TILE];       //  4 KB
@@ -1378,6 +1393,8 @@ __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(
 	__shared__ uint16_t s_base[REFIT_TILE];    //  2 KB: jobs whose range starts at lo + k, then their exclusive prefix sums
 	__shared__ uint16_t s_round[REFIT_TILE], s_spine[REFIT_TILE], s_map[REFIT_TILE];   // the jobs in breadth-first order; ...; number -> node
 	__shared__ uint8_t s_lvl[REFIT_TILE];
+	__shared__ uint16_t s_rootof[REFIT_TILE];  //  2 KB: the tile root above node lo + k (its place in s_roots)
+	__shared__ uint32_t s_rdepth[REFIT_TILE / 2];   //  2 KB: deepest level below each root
 	__shared__ int s_roots[REFIT_TILE / 2];    //  2 KB: the tile roots
 	__shared__ uint32_t s_nroots, s_count;
 	const int lo = (int)blockIdx.x * REFIT_TILE;
@@ -1392,7 +1409,7 @@ __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(
 	__syncthreads();
 	PHASE_MARK(1);
 	if (t < 64) {
-		const uint32_t cnt = tile_bfs(lo, s_lr, s_area, s_start, s_roots, s_nroots, tile_parent, s_round, s_spine, s_lvl, reinterpret_cast<uint32_t *>(s_base));
+		const uint32_t cnt = tile_bfs(lo, s_lr, s_area, s_start, s_roots, s_nroots, s_round, s_spine, s_lvl, reinterpret_cast<uint32_t *>(s_base), s_rootof, s_rdepth);
 		// pre-order numbers: jobs that start further left (prefix sums over the per-start counters, 16 per lane) + jobs above
 		// with the same start
 		uint32_t sum = 0;
@@ -1411,18 +1428,14 @@ __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(
 	const uint32_t count = s_count;
 	const uint32_t base = node_offset + tile_base[blockIdx.x];
 #define TILE_LOCAL(k_) ((uint32_t)s_base[s_start[k_]] + (uint32_t)s_spine[k_])
-	// where each root hangs: child `slot` of node `pn`, made by the collapse of the levels above (tile_parent)
-	for (uint32_t r = (uint32_t)t; r < s_nroots; r += TILE_THREADS) {
-		const unsigned long long w = tile_parent[s_roots[r]];
-		const uint32_t pn = (uint32_t)(w >> 2), slot = (uint32_t)w & 3u;
-		if (pn < node_cap) nodes[pn].child[slot] = base + TILE_LOCAL(s_roots[r] - lo);
-	}
+	// the number of each root's node and the levels of its subtree, for the node above the tiles that it hangs in (k_top_finish)
+	for (uint32_t r = (uint32_t)t; r < s_nroots; r += TILE_THREADS)
+		root_info[s_roots[r]] = ((unsigned long long)(s_rdepth[r] + 1u) << 32) | (unsigned long long)(base + TILE_LOCAL(s_roots[r] - lo));
 	// number -> binary node (s_map), then the nodes themselves, dense: thread j makes wide nodes j, j + blockDim, ... of the tile
 	for (uint32_t j = (uint32_t)t; j < count; j += TILE_THREADS) { const uint32_t k = s_round[j]; s_map[TILE_LOCAL(k)] = (uint16_t)k; }
 	__syncthreads();
 	PHASE_MARK(3);
 	bool misfit = false;
-	uint32_t deepest = 0;
 	// (every lane of a wave goes through the loop as long as one of them has a node to make: the stores below are shared)
 	for (uint32_t j = (uint32_t)t; (j & ~63u) < count; j += TILE_THREADS) {
 		const bool made = j < count;
@@ -1500,12 +1513,9 @@ __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(
 				if (jn < count && base + jn < node_cap) reinterpret_cast<uint4 *>(qnodes + base + jn)[lane & 3u] = pq[k];
 			}
 		}
-		if (made) deepest = deepest > (uint32_t)s_lvl[bk] + 1u ? deepest : (uint32_t)s_lvl[bk] + 1u;      // (the scene's depth counts levels from 1)
 	}
 #undef TILE_LOCAL
 	if (misfit) atomicAdd(&consts->qnode_misfits, 1u);
-	for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(deepest, o); deepest = deepest > u ? deepest : u; }
-	if ((t & 63) == 0 && deepest) atomicMax(depth_word, deepest);
 #ifdef RTK_TILE_PHASES
 	__syncthreads();
 	PHASE_MARK(4);
@@ -1517,6 +1527,54 @@ __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(
 		atomicMax(&g_tile_phase[7], ((ph[4] - ph[3]) << 32) | count);
 	}
 #endif
+}
+
+// The nodes above the tiles, from the workspace to their places in the scene's arrays, complete: node 0 stays the root, the
+// others go BEHIND the tiles' nodes ([1, 1 + *tiles_total): k_collapse_tile, which ran beside the collapse of these) -- so
+// neither of the two collapses has to wait for the other one's node count. Child words: a node above the tiles moves with
+// the rest, a tile root gets the number k_collapse_tile gave it (root_info), leaves stay. Order words, compressed copy, scene
+// bound (node 0) as k_quantize does them; the depth of the tree = the deepest (level of a node here + levels of a tile subtree).
+__global__ void __launch_bounds__(256) k_top_finish(const DevNode *top, const uint4 *tile_refs, const uint32_t *level, uint32_t count, const uint32_t *tiles_total,
+	const unsigned long long *root_info, DevNode *nodes, DevNodeQ *qnodes, uint32_t node_cap, DevSceneConsts *consts, uint32_t *depth_word)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t deepest = 0u;
+	bool misfit = false;
+	if (i < count) {
+		const uint32_t shift = *tiles_total;
+		DevNode nd = top[i];
+		const uint4 tr4 = tile_refs[i];
+		const uint32_t tr[4] = { tr4.x, tr4.y, tr4.z, tr4.w };
+		const uint32_t lvl = level[i];
+		deepest = lvl + 1u;                                                       // (the scene's depth counts levels from 1)
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if (tr[k]) {
+				const unsigned long long info = root_info[tr[k] - 1u];
+				nd.child[k] = (uint32_t)info;
+				const uint32_t d = lvl + 1u + (uint32_t)(info >> 32);
+				deepest = deepest > d ? deepest : d;
+			} else if (nd.child[k] != RTK_REF_NONE && !(nd.child[k] & RTK_REF_LEAF)) nd.child[k] += shift;   // (never the root)
+		}
+		child_order(nd, nd.order);
+		if (i == 0u) {
+			float b = 0.0f;
+			for (int k = 0; k < 4; k++) {
+				if (nd.child[k] == RTK_REF_NONE) continue;
+				const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
+				for (int c = 0; c < 6; c++) b = (fabsf(v[c]) <= 3.0e38f) ? fmaxf(b, fabsf(v[c])) : INFINITY;   // NaN / inf planes: no bound
+			}
+			consts->bound_raw = b;
+			consts->bound_abs = fmaxf(b, 1.0f);
+		}
+		DevNodeQ q;
+		misfit = !quantize_node(nd, q);
+		const uint32_t at = i ? i + shift : 0u;
+		if (at < node_cap) { nodes[at] = nd; qnodes[at] = q; }
+	}
+	if (misfit) atomicAdd(&consts->qnode_misfits, 1u);
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(deepest, o); deepest = deepest > u ? deepest : u; }
+	if ((threadIdx.x & 63u) == 0u && deepest) atomicMax(depth_word, deepest);
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -2096,29 +2154,29 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	uint32_t *d_tile_nclimb = ar.take<uint32_t>(num_tiles + 1u);
 	int *d_climb_idx = reinterpret_cast<int *>(d_arrive);
 	if (hipMemsetAsync(d_half, 0, (size_t)n * 8, bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
+	if (tile_mode && rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();    // (cleared before the second stream forks off: the callee's error text stands)
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
 	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
 		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area, d_depth_word + 1);
 	hipLaunchKernelGGL(k_refit_top, dim3(num_tiles), dim3(64), 0, bs, d_tris, (int)n, keys, d_climbers, d_climb_idx, d_tile_nclimb, d_half, d_bin, d_lr, d_range,
 		d_root, bp, tile_mode);
+	bool forked = false;
+	hipStream_t cs = bs;
 	if (tile_mode) {
-		// how many wide nodes every tile makes, and where they start: needed by k_collapse_tile only, which runs after the collapse of
-		// the nodes above the tiles -- a dozen small launches with host round trips between them. On a stream of their own the two
-		// kernels run beside those (they read what the refit wrote, the top collapse writes nothing of it): 0.1 ms at 10M triangles.
+		// how many wide nodes every tile makes, and where they start, then (below, once the node arrays are allocated) the tiles' nodes
+		// themselves: on a stream of their own, beside the collapse of the nodes above the tiles -- a dozen small launches with host
+		// round trips between them, 0.2 ms at 10M triangles in which the chip would have next to nothing to do.
 		if (!ws.side && (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ws.fork, hipEventDisableTiming) != hipSuccess ||
 				hipEventCreateWithFlags(&ws.join, hipEventDisableTiming) != hipSuccess)) {
 			(void)hipGetLastError();
 			if (ws.side) (void)hipStreamDestroy(ws.side);
 			ws.side = nullptr;                       // (events created so far are kept for the next attempt: a handful of bytes)
 		}
-		const bool forked = ws.side && hipEventRecord(ws.fork, bs) == hipSuccess && hipStreamWaitEvent(ws.side, ws.fork, 0) == hipSuccess;
-		const hipStream_t cs = forked ? ws.side : bs;
+		forked = ws.side && hipEventRecord(ws.fork, bs) == hipSuccess && hipStreamWaitEvent(ws.side, ws.fork, 0) == hipSuccess;
+		cs = forked ? ws.side : bs;
 		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, cs, (int)n, d_lr, d_range, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_tile_count);
 		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, cs, d_tile_count, num_tiles, d_tile_base);
-		if (forked) {
-			side_busy = true;
-			if (hipEventRecord(ws.join, ws.side) != hipSuccess) return fail("event record");
-		}
+		if (forked) side_busy = true;
 	}
 	if (hipGetLastError() != hipSuccess) return fail("refit");
 	stage("refit");
@@ -2130,10 +2188,18 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	cb.info = ar.take<uint32_t>(n);
 	cb.sums = ar.take<uint32_t>(collapse_blocks);
 	LevelState *d_ring = ar.take<LevelState>(COLLAPSE_RING);
-	DevNode *d_nodes_tmp = tile_mode ? (DevNode *)nullptr : ar.take<DevNode>(n);
-	if (!tile_mode && !d_nodes_tmp) return fail("workspace too small (internal error)");
-	// pass 2's hand-over words are dead once it has run: the same array tells k_collapse_tile where each tile root hangs
-	unsigned long long *d_tile_parent = tile_mode ? d_half : (unsigned long long *)nullptr;
+	// n nodes' worth of workspace: every node of the tree without tile mode (worst case). In tile mode it holds the nodes above
+	// the tiles until k_top_finish moves them to their places (at most n / 2 of them; a tree with more goes the other way), their
+	// tile-root and level words, and a word per binary node for what k_collapse_tile tells k_top_finish about the tile roots.
+	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
+	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
+	// (RTK_AMD_TOP_CAP: a smaller capacity, to drive the way back to the level-by-level collapse from tests)
+	const uint32_t top_cap = getenv("RTK_AMD_TOP_CAP") ? std::min<uint32_t>(n / 2u, (uint32_t)atoi(getenv("RTK_AMD_TOP_CAP"))) : n / 2u;
+	uint4 *d_top_refs = reinterpret_cast<uint4 *>(d_nodes_tmp + top_cap);
+	uint32_t *d_top_level = reinterpret_cast<uint32_t *>(d_top_refs + top_cap);
+	unsigned long long *d_root_info = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_nodes_tmp) + padded((size_t)top_cap * (sizeof(DevNode) + 16u + 4u)));
+	static_assert(sizeof(DevNode) == 128, "the carving above: n / 2 * 148 + 8 n + padding <= 128 n");
+	TopAux top_aux = { tile_mode ? d_top_refs : (uint4 *)nullptr, tile_mode ? d_top_level : (uint32_t *)nullptr };
 	LevelState h_state = {};
 	// The node arrays of the scene, [DevNode x node_cap | DevNodeQ x node_cap], are allocated now -- the GPU is still busy
 	// with the refit -- at the size 4-wide trees over n triangles usually have (0.47 n on the benchmark scenes), and the
@@ -2153,14 +2219,14 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		for (uint64_t c = COLLAPSE_SMALL_JOBS; c < jobs_hint; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, d_tile_parent);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, top_aux);
 			for (unsigned k = 0; k < big_levels; k++) {
 				// number the level of ring entry `step` (-> entry step + 1: the next level, not opened yet), then open that
 				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, target, cap);
 				step++;
-				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, target, cap, d_tile_parent);
+				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, target, cap, top_aux);
 			}
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, d_tile_parent);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, top_aux);
 			if (hipGetLastError() != hipSuccess ||
 				hipMemcpyAsync(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipStreamSynchronize(bs) != hipSuccess) return false;
@@ -2171,26 +2237,36 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	};
 	uint32_t total_nodes = 0, depth = 0;
 	uint32_t h_equal_codes = 0;          // sorted neighbours with one and the same Morton code (counted by k_refit_tile)
+	bool tiles_done = false;
 	if (tile_mode) {
-		if (rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();             // (the callee's error text stands)
 		DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
 		uint32_t h_tail[2] = { 0u, 0u };      // { wide nodes of all tiles, deepest level }
+		uint32_t top_nodes = 0;
 		for (int attempt = 0;; attempt++) {
-			if (!node_mem) {
-				// (second attempt, or the estimate could not be allocated: the exact size is known by now or will be after one dry round)
-				if (attempt == 0) { node_cap = 0; }
-			}
+			// (no node memory: the estimate could not be allocated -- a dry round gives the exact size)
+			if (!node_mem) node_cap = 0;
 			DevNode *d_nodes_ = (DevNode *)node_mem;
-			// the nodes above the tiles: ~15 tile roots per tile hang below them
-			if (!run_collapse(d_nodes_, (uint32_t)node_cap, (uint64_t)num_tiles * 16u)) return fail("collapse");
-			const uint32_t top_nodes = h_state.total_nodes;
-			if (side_busy && hipStreamWaitEvent(bs, ws.join, 0) != hipSuccess) return fail("stream wait");      // the tile counts and bases are there
-			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, bs, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_tile_parent,
-				d_tile_base, top_nodes, d_nodes_, (DevNodeQ *)(d_nodes_ + node_cap), (uint32_t)node_cap, consts, d_depth_word);
+			DevNodeQ *d_qnodes_ = (DevNodeQ *)(d_nodes_ + node_cap);
+			// the tiles' nodes, numbers 1 ... (0 is the root): beside the collapse of the nodes above them the first time
+			const hipStream_t ts = attempt == 0 ? cs : bs;
+			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, ts, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_root_info,
+				d_tile_base, 1u, d_nodes_, d_qnodes_, (uint32_t)node_cap, consts);
+			if (hipGetLastError() != hipSuccess) return fail("tile collapse launch");
+			if (attempt == 0) {
+				if (forked && hipEventRecord(ws.join, ws.side) != hipSuccess) return fail("event record");
+				// the nodes above the tiles (~4 per tile; ~15 tile roots per tile hang below them), into the workspace
+				if (!run_collapse(d_nodes_tmp, top_cap, (uint64_t)num_tiles * 16u)) return fail("collapse");
+				top_nodes = h_state.total_nodes;
+				if (forked && hipStreamWaitEvent(bs, ws.join, 0) != hipSuccess) return fail("stream wait");
+				if (top_nodes > top_cap) break;           // (more of them than the workspace holds: everything level by level, below)
+			}
+			hipLaunchKernelGGL(k_top_finish, dim3((top_nodes + 255u) / 256u), dim3(256), 0, bs, d_nodes_tmp, d_top_refs, d_top_level, top_nodes, d_tile_base + num_tiles, d_root_info,
+				d_nodes_, d_qnodes_, (uint32_t)node_cap, consts, d_depth_word);
 			if (hipGetLastError() != hipSuccess ||
 				hipMemcpyAsync(&h_tail[0], d_tile_base + num_tiles, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipMemcpyAsync(&h_tail[1], d_depth_word, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
+				hipMemcpyAsync(&ds->consts_readback, consts, sizeof(DevSceneConsts), hipMemcpyDeviceToHost, bs) != hipSuccess ||
 				hipStreamSynchronize(bs) != hipSuccess) return fail("tile collapse");
 #ifdef RTK_TILE_PHASES
 			{
@@ -2210,24 +2286,32 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 					hc[0], hc[1], hc[num_tiles - 1], hb[0], hb[1], hb[num_tiles]);
 			}
 			total_nodes = top_nodes + h_tail[0];
-			depth = h_tail[1] > h_state.depth ? h_tail[1] : h_state.depth;
+			depth = h_tail[1];
 			if (total_nodes <= node_cap) {
-				// order words and compressed copies of the nodes above the tiles (their child words are complete only now), scene constants
 				ds->view.nodes = d_nodes_;
+				ds->view.qnodes = d_qnodes_;
 				ds->view.num_nodes = total_nodes;
-				if (rtk_quantize_nodes(ds, bs, nullptr, (DevNodeQ *)(d_nodes_ + node_cap), 0.0f, top_nodes ? top_nodes : 1u, true) != RTK_AMD_OK) return give_up();
+				ds->first_top = 1u + h_tail[0];
+				tiles_done = true;
 				break;
 			}
 			if (attempt > 0) return fail("collapse (internal error: node count changed between two runs)");
-			// the estimate was too small: an exact allocation, and once more (both collapses are deterministic)
+			// the estimate was too small: an exact allocation, and the tiles and the move once more (the nodes above the tiles stay
+			// where they are in the workspace; every pass is deterministic)
 			if (node_mem) { ds->allocs.pop_back(); (void)hipFree(node_mem); node_mem = nullptr; }     // it was the last one pushed
 			node_cap = total_nodes;
 			if (hipMalloc(&node_mem, node_cap * (sizeof(DevNode) + sizeof(DevNodeQ))) != hipSuccess) return fail("out of device memory");
 			ds->allocs.push_back(node_mem);
 			if (hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 4, bs) != hipSuccess) return fail("memset");
 		}
-		stage("collapse");
-	} else {
+		if (tiles_done) stage("collapse");
+		else {
+			// (the other way needs the level-by-level kernels without their tile-mode arguments, and clean counters)
+			top_aux = TopAux{ nullptr, nullptr };
+			if (hipMemsetAsync(d_depth_word, 0, 4, bs) != hipSuccess) return fail("memset");
+		}
+	}
+	if (!tiles_done) {
 		bool in_place = node_mem != nullptr;
 		if (!run_collapse(in_place ? (DevNode *)node_mem : d_nodes_tmp, in_place ? (uint32_t)node_cap : n, n)) return fail("collapse");
 		if (in_place && h_state.total_nodes > node_cap) {
@@ -2251,7 +2335,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap)) != RTK_AMD_OK) return give_up();
 	}
 	ds->total_bytes += node_cap * (sizeof(DevNode) + sizeof(DevNodeQ));
-	if (!tile_mode && hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess) return fail("copy");
+	if (!tiles_done && hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess) return fail("copy");
 	if (hipStreamSynchronize(bs) != hipSuccess || (side_busy && hipStreamSynchronize(ws.side) != hipSuccess)) return fail("sync");   // the workspace is handed back below
 	rtk_quantize_finish(ds);
 

@@ -125,6 +125,7 @@ struct rtk_dev_scene {
 	std::vector<uint64_t> mesh_base;  // num_meshes + 1
 	uint32_t max_depth = 0;
 	uint32_t stack_entries = 0;
+	uint32_t first_top = 0;                // device build, tile collapse: nodes [1, first_top) are the tiles', 0 and [first_top, n) the ones above them (0: one run)
 	uint64_t total_bytes = 0;
 	double build_ms = 0.0;
 	double big_leaf_fraction = 0.0;        // leaves of more than three triangles (uploads; device builds make ~none): the assembly packet kernel hands those tiles back

@@ -9,8 +9,10 @@
 //     that contain but are not the exact union (legal, the device builder never produces them);
 //   - every triangle slot belongs to exactly one leaf, every primitive id occurs exactly once and
 //     prim_slot is its inverse;
-//   - every node except the root is referenced exactly once, children come after their parent
-//     (breadth-first numbering, hence no cycles);
+//   - every node except the root is referenced exactly once, children come after their parent (hence no cycles). A tree
+//     from the device build's tile collapse has two runs of numbers: the nodes of the refit tiles [1, first_top), and the
+//     nodes above the tiles, 0 and [first_top, n); inside each run children come after their parent, a node above the tiles
+//     may also point down into the tiles' run, a tile's node never out of it (still no cycles);
 //   - leaf headers: 1..63 triangles (rtk.c:188), count in the first record, end flag on the last.
 // A content hash (order-sensitive per element, combined commutatively) tells two builds apart.
 #include "rtk_dev.h"
@@ -35,7 +37,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 	return x;
 }
 
-__global__ void k_check_nodes(DevSceneView sc, uint32_t *slot_seen, uint32_t *node_seen, unsigned long long *c)
+__global__ void k_check_nodes(DevSceneView sc, uint32_t first_top, uint32_t *slot_seen, uint32_t *node_seen, unsigned long long *c)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= sc.num_nodes) return;
@@ -89,7 +91,10 @@ __global__ void k_check_nodes(DevSceneView sc, uint32_t *slot_seen, uint32_t *no
 				}
 			}
 		} else {
-			if (ref >= sc.num_nodes || ref <= i) { report(c, C_BAD_REF, i); continue; }
+			// (first_top 0: one run of numbers)
+			const bool tile_node = i != 0u && i < first_top, tile_child = ref != 0u && ref < first_top;
+			const bool order_ok = tile_node ? (ref > i && tile_child) : (ref > i || tile_child);
+			if (ref >= sc.num_nodes || !order_ok) { report(c, C_BAD_REF, i); continue; }
 			atomicAdd(&node_seen[ref], 1u);
 			const DevNode ch = sc.nodes[ref];
 			for (int q = 0; q < 4; q++) {
@@ -160,7 +165,7 @@ extern "C" int rtk_dev_scene_validate(const rtk_dev_scene *ds, rtk_dev_scene_che
 		h[C_FIRST_BAD] = ~0ull;
 		if (hipMemset(d_seen, 0, words * 4) != hipSuccess || hipMemcpy(d_c, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { rc = RTK_AMD_ERR_HIP; break; }
 		uint32_t *slot_seen = d_seen, *node_seen = d_seen + v.num_tris, *prim_seen = node_seen + v.num_nodes;
-		hipLaunchKernelGGL(k_check_nodes, dim3((v.num_nodes + 127u) / 128u), dim3(128), 0, 0, v, slot_seen, node_seen, d_c);
+		hipLaunchKernelGGL(k_check_nodes, dim3((v.num_nodes + 127u) / 128u), dim3(128), 0, 0, v, ds->first_top, slot_seen, node_seen, d_c);
 		if (v.num_tris) hipLaunchKernelGGL(k_check_slots, dim3((v.num_tris + 255u) / 256u), dim3(256), 0, 0, v, slot_seen, prim_seen, d_c);
 		const uint32_t m = v.num_nodes > v.num_prims ? v.num_nodes : v.num_prims;
 		// a scene built here holds every primitive of its meshes; an uploaded blob may leave ids unused

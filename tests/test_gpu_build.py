@@ -557,6 +557,23 @@ def test_tile_local_collapse_at_small_sizes(api, oracle, n, monkeypatch):
     ds_level = api.DeviceScene.build([dict(positions=tris)])
     ok2, c2 = ds_level.validate()
     assert ok2 and c2["content_hash"] != c["content_hash"]          # another (valid) tree: tile roots are never opened from above
+    # a node estimate that is far too small: the tiles' nodes and the move of the nodes above them are done once more into an
+    # exact allocation -- the very same tree
+    monkeypatch.setenv("RTK_AMD_TILE_COLLAPSE_MIN", "0")
+    monkeypatch.setenv("RTK_AMD_NODE_ESTIMATE_DIV", "16")
+    ds_r = api.DeviceScene.build([dict(positions=tris)])
+    ok3, c3 = ds_r.validate()
+    assert ok3 and c3["content_hash"] == c["content_hash"], c3
+    monkeypatch.delenv("RTK_AMD_NODE_ESTIMATE_DIV")
+    # more nodes above the tiles than their stretch of the workspace holds (forced: two): the build goes the level-by-level way
+    monkeypatch.setenv("RTK_AMD_TOP_CAP", "2")
+    # (a valid tree of its own: the refit of a tile-mode build keeps subtrees that cross a tile border from becoming one leaf)
+    ds_f = api.DeviceScene.build([dict(positions=tris)])
+    ok4, c4 = ds_f.validate()
+    assert ok4 and c4["triangles_checked"] == n and c4["loose_boxes"] == 0, c4
+    assert api.DeviceScene.build([dict(positions=tris)]).validate()[1]["content_hash"] == c4["content_hash"]
+    _same_as_oracle(oracle, _as_blob(oracle, ds_f.export_blob()), ds_f, synth.rays_config1(4096), "top of the tree level by level vs oracle on exported blob")
+    monkeypatch.delenv("RTK_AMD_TOP_CAP")
     rays = synth.rays_config1(16384)
     blob = _as_blob(oracle, ds.export_blob())
     _same_as_oracle(oracle, blob, ds, rays, "tile-local collapse vs oracle on exported blob")
