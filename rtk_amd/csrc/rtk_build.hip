@@ -687,9 +687,9 @@ __device__ __forceinline__ unsigned long long meet_word(int ref, int end) { retu
 
 __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
 	BinNode *bin, Climb *climbers, unsigned long long *meet, int *climb_idx, uint32_t *tile_nclimb, int *root, BuildParams bp, float *area,
-	uint32_t *equal_codes)
+	uint32_t *equal_codes, int *root_list, uint32_t *tile_nroots)
 {
-	__shared__ uint32_t s_nclimb;
+	__shared__ uint32_t s_nclimb, s_nroot;
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
 	__shared__ uint32_t s_arrive[REFIT_TILE];
 	__shared__ int2 s_lr[REFIT_TILE];                            // children of node lo + k (x left, y right)
@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
 	const int t = (int)threadIdx.x;
 	s_arrive[t] = 0u;
-	if (t == 0) s_nclimb = 0u;
+	if (t == 0) { s_nclimb = 0u; s_nroot = 0u; }
 	s_lr[t] = make_int2(INT_MIN, INT_MIN);
 	int my_delta = -1;
 	if (lo + t - 1 <= hi) s_delta[t] = my_delta = key_delta(keys, n, lo + t - 1);
@@ -743,7 +743,11 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 		// looking at every triangle: their positions, packed at the start of the tile's stretch of climb_idx (any order: the tree
 		// does not depend on who climbs first). (Round 4 wrote all 1024 records of a tile, 12 bytes per triangle, and both
 		// collapse kernels read them all back to find the two dozen that are there.)
-		if (left_over.cur_ref != INT_MIN) { climbers[i] = left_over; climb_idx[lo + (int)atomicAdd(&s_nclimb, 1u)] = i; }
+		if (left_over.cur_ref != INT_MIN) {
+			climbers[i] = left_over; climb_idx[lo + (int)atomicAdd(&s_nclimb, 1u)] = i;
+			// tile mode: the subtree it carried to the border is one of the tile's roots (below), unless it is one leaf
+			if (root_list && left_over.cur_ref >= 0 && open_area(cur) > 0.0f) root_list[lo + (int)atomicAdd(&s_nroot, 1u)] = left_over.cur_ref;
+		}
 	}
 	__syncthreads();
 	if (t == 0) tile_nclimb[blockIdx.x] = s_nclimb;
@@ -755,17 +759,28 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 		const int rec = m >> 1;
 		if (lo + rec < hi && s_arrive[rec] == 2u) reinterpret_cast<uint4 *>(bin + lo)[m] = reinterpret_cast<const uint4 *>(s_bin)[m];
 	}
+	// The tile's ROOTS (tile mode): the largest subtrees that lie inside the tile -- what its climbers carried to the border
+	// (above) and the half that is here of a node whose other child arrives in pass 2 -- are all known now. The tile-local
+	// collapse (k_count_tile, k_collapse_tile) reads this list and the records of the nodes that are complete here, nothing
+	// that pass 2 writes: it runs beside pass 2 and the collapse of the nodes above the tiles. area < 0: not a node to open
+	// (one leaf: open_area; not complete in this pass: -1).
 	if (i < hi && s_arrive[t] == 2u) {
 		if (area) area[i] = open_area(s_bin[t]);      // what the tile-local collapse ranks children by (4 bytes instead of the 32-byte record)
 		lr[i] = s_lr[t];
 		range[i] = make_uint2((uint32_t)s_rl[t], (uint32_t)s_rr[t]);
-	} else if (i < hi && s_arrive[t] == 1u) {
-		// one child came, the other one's subtree reaches into a neighbouring tile and arrives in pass 2: hand the half that
-		// is here over in the form pass 2 uses (plain stores, the kernel boundary publishes them)
-		const bool left_here = s_lr[t].x != INT_MIN;
-		const int ref = left_here ? s_lr[t].x : s_lr[t].y, end = left_here ? s_rl[t] : s_rr[t];
-		meet[i] = meet_word(ref, end);
+	} else if (i < hi) {
+		if (area) area[i] = -1.0f;
+		if (s_arrive[t] == 1u) {
+			// one child came, the other one's subtree reaches into a neighbouring tile and arrives in pass 2: hand the half that
+			// is here over in the form pass 2 uses (plain stores, the kernel boundary publishes them)
+			const bool left_here = s_lr[t].x != INT_MIN;
+			const int ref = left_here ? s_lr[t].x : s_lr[t].y, end = left_here ? s_rl[t] : s_rr[t];
+			meet[i] = meet_word(ref, end);
+			if (root_list && ref >= 0 && open_area(s_bin[ref - lo]) > 0.0f) root_list[lo + (int)atomicAdd(&s_nroot, 1u)] = ref;
+		}
 	}
+	__syncthreads();
+	if (t == 0 && tile_nroots) tile_nroots[blockIdx.x] = s_nroot;
 }
 
 // exclusive prefix sums of the tiles' wide-node counts (one workgroup; a build has at most n / 1024 tiles); out[num] = total
@@ -1216,20 +1231,20 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 //                    made before: their numbers are written into those nodes' child words.
 #define TILE_THREADS 256       // k_collapse_tile: the first wave marks and numbers, all four finish nodes (k_count_tile: one wave)
 
-// loads the tile's child links and areas into LDS and lists the tile roots (s_roots, *s_nroots; their order does not matter:
-// numbers come from the tree alone): for every node / triangle position of the tile the subtree a triangle carried to the
-// border in pass 1 (its parent's split position lies outside the tile) and the finished child of a node that reaches beyond
-// the tile (its other child arrived in pass 2). Roots are inner nodes with disjoint ranges: at most REFIT_TILE / 2 of them.
+// loads the tile's child links and areas into LDS and its roots (root_list / nroots: k_refit_tile listed them -- the subtrees
+// its climbers carried to the tile's borders and the halves that are in the tile of nodes that reach beyond it; their order does
+// not matter: numbers come from the tree alone. Inner nodes with disjoint ranges: at most REFIT_TILE / 2 of them). Nothing
+// pass 2 writes is used: the area of a node that pass 1 did not complete is -1, and no root's subtree leads to one.
 // (THREADS = the workgroup's size. All of a thread's global loads are issued before the first one is used -- left as a loop the
 // compiler waits for each position's loads before it asks for the next: 16 dependent memory round trips per thread in the
 // 64-thread counting kernel, 22 us of a tile's 118 in k_collapse_tile.)
 template <int THREADS>
-__device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers,
-	const int *climb_idx, uint32_t nclimb, int2 *s_lr, float *s_area, uint16_t *s_start, int *s_roots, uint32_t *s_nroots)
+__device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const uint2 *range, const float *area, const int *root_list, uint32_t nroots,
+	int2 *s_lr, float *s_area, uint16_t *s_start, int *s_roots, uint32_t *s_nroots)
 {
 	constexpr int ITER = REFIT_TILE / THREADS;
 	const int t = (int)threadIdx.x;
-	if (t == 0) *s_nroots = 0u;
+	if (t == 0) *s_nroots = nroots;
 	int2 v_lr[ITER];
 	uint2 v_rg[ITER];
 	float v_a[ITER];
@@ -1237,38 +1252,17 @@ __device__ __forceinline__ void tile_load(int lo, int hi, const int2 *lr, const 
 	for (int q = 0; q < ITER; q++) {
 		const int i = lo + t + q * THREADS;
 		const int ic = i < hi ? i : (hi > lo ? hi - 1 : lo);       // (a position that exists: the values of positions beyond the tile are not used)
-		v_lr[q] = lr[ic]; v_a[q] = area[ic]; v_rg[q] = range[ic];
+		v_lr[q] = lr[ic]; v_a[q] = area[ic];
+		v_rg[q] = s_start ? range[ic] : make_uint2(0u, 0u);
 	}
-	// the subtrees the tile's climbers carried to its borders (a few to a few dozen: their positions are listed per tile)
-	int v_cl = INT_MIN;
-	if ((uint32_t)t < nclimb) v_cl = climbers[climb_idx[lo + t]].cur_ref;
+	for (uint32_t j = (uint32_t)t; j < nroots; j += THREADS) s_roots[j] = root_list[lo + (int)j];
 #pragma unroll
 	for (int q = 0; q < ITER; q++) {
 		const int k = t + q * THREADS, i = lo + k;
-		uint2 rg = make_uint2((uint32_t)lo, (uint32_t)lo);
-		float a = -1.0f;
-		if (i < hi) { s_lr[k] = v_lr[q]; a = v_a[q]; rg = v_rg[q]; }      // (entries of nodes that are not inside the tile are never followed)
-		else s_lr[k] = make_int2(INT_MIN, INT_MIN);
-		// a node that reaches beyond the tile is marked by an area of -2 for the second step below (it is never opened here)
-		s_area[k] = (i < hi && ((int)rg.x < lo || (int)rg.y > hi)) ? (((int)rg.x >= lo) ? -2.0f : -3.0f) : a;
-		if (s_start) s_start[k] = (uint16_t)((int)rg.x >= lo ? (int)rg.x - lo : 0);
-	}
-	__syncthreads();
-	for (uint32_t j = (uint32_t)t; j < nclimb; j += THREADS) {
-		const int a = j == (uint32_t)t ? v_cl : climbers[climb_idx[lo + (int)j]].cur_ref;
-		if (a >= 0 && s_area[a - lo] > 0.0f) s_roots[atomicAdd(s_nroots, 1u)] = a;
-	}
-#pragma unroll
-	for (int q = 0; q < ITER; q++) {
-		const int k = t + q * THREADS, i = lo + k;
-		if (i < hi && s_area[k] <= -2.0f) {
-			const int2 ch = s_lr[k];
-			// (left child: sorted range [start, i]; right child: [i + 1, end]. At most one of them lies inside the tile: the
-			// left one if the node's range starts inside the tile (-2), else the right one if it ends inside (-3, checked by the
-			// child's own record: a child that reaches beyond the tile carries a mark itself))
-			const int half_ref = s_area[k] == -2.0f ? ch.x : ch.y;
-			if (half_ref >= 0 && half_ref >= lo && half_ref < hi && s_area[half_ref - lo] > 0.0f) s_roots[atomicAdd(s_nroots, 1u)] = half_ref;
-		}
+		// (entries of nodes that are not complete inside the tile are never followed; their ranges may be anything)
+		if (i < hi) { s_lr[k] = v_lr[q]; s_area[k] = v_a[q]; }
+		else { s_lr[k] = make_int2(INT_MIN, INT_MIN); s_area[k] = -1.0f; }
+		if (s_start) s_start[k] = (uint16_t)((i < hi && (int)v_rg[q].x >= lo && (int)v_rg[q].x <= hi) ? (int)v_rg[q].x - lo : 0);
 	}
 	__syncthreads();
 }
@@ -1332,8 +1326,7 @@ __device__ __forceinline__ uint32_t tile_bfs(int lo, const int2 *s_lr, const flo
 	return tail;
 }
 
-__global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const uint2 *range, const float *area, const Climb *climbers, const int *climb_idx,
-	const uint32_t *tile_nclimb, uint32_t *tile_count)
+__global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const float *area, const int *root_list, const uint32_t *tile_nroots, uint32_t *tile_count)
 {
 	__shared__ int2 s_lr[REFIT_TILE];
 	__shared__ float s_area[REFIT_TILE];
@@ -1342,7 +1335,7 @@ __global__ void __launch_bounds__(64) k_count_tile(int n, const int2 *lr, const 
 	__shared__ uint32_t s_nroots;
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;
-	tile_load<64>(lo, hi, lr, range, area, climbers, climb_idx, tile_nclimb[blockIdx.x], s_lr, s_area, nullptr, s_roots, &s_nroots);
+	tile_load<64>(lo, hi, lr, nullptr, area, root_list, tile_nroots[blockIdx.x], s_lr, s_area, nullptr, s_roots, &s_nroots);
 	if (threadIdx.x < 64u) {
 		const uint32_t count = tile_bfs(lo, s_lr, s_area, nullptr, s_roots, s_nroots, s_q, nullptr, nullptr, nullptr, nullptr, nullptr);
 		if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
@@ -1384,7 +1377,7 @@ __device__ unsigned long long g_tile_phase[8];
 #define TILE_WAVES_ATTR
 #endif
 __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(DevTri *tris, int n, const int2 *lr, const uint2 *range, const BinNode *bin, const float *area,
-	const Climb *climbers, const int *climb_idx, const uint32_t *tile_nclimb, unsigned long long *root_info, const uint32_t *tile_base, uint32_t node_offset,
+	const int *root_list, const uint32_t *tile_nroots, unsigned long long *root_info, const uint32_t *tile_base, uint32_t node_offset,
 	DevNode *nodes, DevNodeQ *qnodes, uint32_t node_cap, DevSceneConsts *consts)
 {
 	__shared__ int2 s_lr[REFIT_TILE];          //  8 KB
@@ -1404,7 +1397,7 @@ __global__ void __launch_bounds__(TILE_THREADS) TILE_WAVES_ATTR k_collapse_tile(
 	unsigned long long ph[6];
 #endif
 	PHASE_MARK(0);
-	tile_load<TILE_THREADS>(lo, hi, lr, range, area, climbers, climb_idx, tile_nclimb[blockIdx.x], s_lr, s_area, s_start, s_roots, &s_nroots);
+	tile_load<TILE_THREADS>(lo, hi, lr, range, area, root_list, tile_nroots[blockIdx.x], s_lr, s_area, s_start, s_roots, &s_nroots);
 	for (int k = t; k < REFIT_TILE; k += TILE_THREADS) s_base[k] = 0u;
 	__syncthreads();
 	PHASE_MARK(1);
@@ -1942,7 +1935,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	need += padded((size_t)n * sizeof(BinNode));                                    // bin
 	need += padded((size_t)n * 16) + 2 * padded((size_t)n * 4) + padded(collapse_blocks * 4) + padded(sizeof(LevelState) * COLLAPSE_RING);   // collapse: dec, info, jobs, block sums, ring
 	need += padded((size_t)n * sizeof(DevNode));                                    // nodes (worst case; unused in tile mode)
-	need += 3 * padded(((size_t)n / REFIT_TILE + 4) * 4) + padded(16) + padded((size_t)n * 4);   // tile counts, tile bases, climbers per tile, depth word, areas
+	need += 4 * padded(((size_t)n / REFIT_TILE + 4) * 4) + padded(16) + padded((size_t)n * 4);   // tile counts, tile bases, climbers and roots per tile, depth word, areas
 	Workspace &ws = g_workspace[device];
 	std::lock_guard<std::mutex> ws_lock(ws.mutex);
 	if (ws.cap < need) {
@@ -2153,19 +2146,33 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	// the first n words of d_half
 	uint32_t *d_tile_nclimb = ar.take<uint32_t>(num_tiles + 1u);
 	int *d_climb_idx = reinterpret_cast<int *>(d_arrive);
+	// n nodes' worth of workspace: every node of the tree without tile mode (worst case). In tile mode it holds the nodes above
+	// the tiles until k_top_finish moves them to their places (at most n / 2 of them; a tree with more goes the other way), their
+	// tile-root and level words, a word per binary node for what k_collapse_tile tells k_top_finish about the tile roots, and
+	// the tiles' lists of roots (k_refit_tile).
+	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
+	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
+	// (RTK_AMD_TOP_CAP: a smaller capacity, to drive the way back to the level-by-level collapse from tests)
+	const uint32_t top_cap = getenv("RTK_AMD_TOP_CAP") ? std::min<uint32_t>(n / 2u, (uint32_t)atoi(getenv("RTK_AMD_TOP_CAP"))) : n / 2u;
+	uint4 *d_top_refs = reinterpret_cast<uint4 *>(d_nodes_tmp + top_cap);
+	uint32_t *d_top_level = reinterpret_cast<uint32_t *>(d_top_refs + top_cap);
+	unsigned long long *d_root_info = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_nodes_tmp) + padded((size_t)top_cap * (sizeof(DevNode) + 16u + 4u)));
+	int *d_root_list = reinterpret_cast<int *>(d_root_info + n);
+	static_assert(sizeof(DevNode) == 128, "the carving above: n / 2 * 148 + 8 n + 4 n + padding <= 128 n");
+	uint32_t *d_tile_nroots = ar.take<uint32_t>(num_tiles + 1u);
 	if (hipMemsetAsync(d_half, 0, (size_t)n * 8, bs) != hipSuccess || hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
 	if (tile_mode && rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();    // (cleared before the second stream forks off: the callee's error text stands)
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
 	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
-		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area, d_depth_word + 1);
-	hipLaunchKernelGGL(k_refit_top, dim3(num_tiles), dim3(64), 0, bs, d_tris, (int)n, keys, d_climbers, d_climb_idx, d_tile_nclimb, d_half, d_bin, d_lr, d_range,
-		d_root, bp, tile_mode);
+		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area, d_depth_word + 1, tile_mode ? d_root_list : (int *)nullptr,
+		tile_mode ? d_tile_nroots : (uint32_t *)nullptr);
 	bool forked = false;
 	hipStream_t cs = bs;
 	if (tile_mode) {
 		// how many wide nodes every tile makes, and where they start, then (below, once the node arrays are allocated) the tiles' nodes
-		// themselves: on a stream of their own, beside the collapse of the nodes above the tiles -- a dozen small launches with host
-		// round trips between them, 0.2 ms at 10M triangles in which the chip would have next to nothing to do.
+		// themselves: on a stream of their own, beside pass 2 of the refit and the collapse of the nodes above the tiles -- a chain of
+		// latency-bound launches with host round trips between them, 0.3 ms at 10M triangles in which the chip would have next to
+		// nothing to do. (The tiles' kernels read what pass 1 wrote and nothing that pass 2 writes: k_refit_tile lists the roots.)
 		if (!ws.side && (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ws.fork, hipEventDisableTiming) != hipSuccess ||
 				hipEventCreateWithFlags(&ws.join, hipEventDisableTiming) != hipSuccess)) {
 			(void)hipGetLastError();
@@ -2174,10 +2181,12 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		}
 		forked = ws.side && hipEventRecord(ws.fork, bs) == hipSuccess && hipStreamWaitEvent(ws.side, ws.fork, 0) == hipSuccess;
 		cs = forked ? ws.side : bs;
-		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, cs, (int)n, d_lr, d_range, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_tile_count);
+		hipLaunchKernelGGL(k_count_tile, dim3(num_tiles), dim3(64), 0, cs, (int)n, d_lr, d_area, d_root_list, d_tile_nroots, d_tile_count);
 		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, cs, d_tile_count, num_tiles, d_tile_base);
 		if (forked) side_busy = true;
 	}
+	hipLaunchKernelGGL(k_refit_top, dim3(num_tiles), dim3(64), 0, bs, d_tris, (int)n, keys, d_climbers, d_climb_idx, d_tile_nclimb, d_half, d_bin, d_lr, d_range,
+		d_root, bp, tile_mode);
 	if (hipGetLastError() != hipSuccess) return fail("refit");
 	stage("refit");
 
@@ -2188,17 +2197,6 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	cb.info = ar.take<uint32_t>(n);
 	cb.sums = ar.take<uint32_t>(collapse_blocks);
 	LevelState *d_ring = ar.take<LevelState>(COLLAPSE_RING);
-	// n nodes' worth of workspace: every node of the tree without tile mode (worst case). In tile mode it holds the nodes above
-	// the tiles until k_top_finish moves them to their places (at most n / 2 of them; a tree with more goes the other way), their
-	// tile-root and level words, and a word per binary node for what k_collapse_tile tells k_top_finish about the tile roots.
-	DevNode *d_nodes_tmp = ar.take<DevNode>(n);
-	if (!d_nodes_tmp) return fail("workspace too small (internal error)");
-	// (RTK_AMD_TOP_CAP: a smaller capacity, to drive the way back to the level-by-level collapse from tests)
-	const uint32_t top_cap = getenv("RTK_AMD_TOP_CAP") ? std::min<uint32_t>(n / 2u, (uint32_t)atoi(getenv("RTK_AMD_TOP_CAP"))) : n / 2u;
-	uint4 *d_top_refs = reinterpret_cast<uint4 *>(d_nodes_tmp + top_cap);
-	uint32_t *d_top_level = reinterpret_cast<uint32_t *>(d_top_refs + top_cap);
-	unsigned long long *d_root_info = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_nodes_tmp) + padded((size_t)top_cap * (sizeof(DevNode) + 16u + 4u)));
-	static_assert(sizeof(DevNode) == 128, "the carving above: n / 2 * 148 + 8 n + padding <= 128 n");
 	TopAux top_aux = { tile_mode ? d_top_refs : (uint4 *)nullptr, tile_mode ? d_top_level : (uint32_t *)nullptr };
 	LevelState h_state = {};
 	// The node arrays of the scene, [DevNode x node_cap | DevNodeQ x node_cap], are allocated now -- the GPU is still busy
@@ -2249,7 +2247,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 			DevNodeQ *d_qnodes_ = (DevNodeQ *)(d_nodes_ + node_cap);
 			// the tiles' nodes, numbers 1 ... (0 is the root): beside the collapse of the nodes above them the first time
 			const hipStream_t ts = attempt == 0 ? cs : bs;
-			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, ts, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_climbers, d_climb_idx, d_tile_nclimb, d_root_info,
+			hipLaunchKernelGGL(k_collapse_tile, dim3(num_tiles), dim3(TILE_THREADS), 0, ts, d_tris, (int)n, d_lr, d_range, d_bin, d_area, d_root_list, d_tile_nroots, d_root_info,
 				d_tile_base, 1u, d_nodes_, d_qnodes_, (uint32_t)node_cap, consts);
 			if (hipGetLastError() != hipSuccess) return fail("tile collapse launch");
 			if (attempt == 0) {
