@@ -2132,12 +2132,13 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	// tile mode (more than one refit tile): the subtrees inside a tile are collapsed by k_collapse_tile, only the nodes above
 	// them go through the level-by-level collapse.
 	const uint32_t num_tiles = (n + REFIT_TILE - 1u) / REFIT_TILE;
-	// Measured on MI355X (profiles/r03_build_timing.log): 2.84 against 3.1 ms at 10M triangles, 1.94 / 2.05 at 6M, 1.48 / 1.50 at 4M,
-	// 1.23 / 1.20 at 3M, 0.69 / 0.62 at 1M -- the fixed cost of the extra launches (count, scan, the small top collapse) is not
-	// earned back below ~3.5 million triangles, where tile mode starts. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read per build)
-	// moves that: 0 = whenever there are two tiles, a huge value = never (everything level by level, the round-2 path: A/B).
+	// Measured on MI355X (profiles/r05_build_timing.log, level by level / tile mode): 0.47 / 0.46 ms at 0.5M triangles, 0.555 / 0.540
+	// at 1M, 0.785 / 0.748 at 2M, 1.005 / 0.935 at 3M -- since the tiles' kernels run beside pass 2 and the top collapse, tile mode
+	// is never slower; its trees have ~2 % more nodes (tile roots are never opened from above: ~1 % more node visits per ray), so
+	// it starts where the build time it saves is worth more than that: 1.5M triangles. RTK_AMD_TILE_COLLAPSE_MIN (triangles; read
+	// per build) moves that: 0 = whenever there are two tiles, a huge value = never (everything level by level: A/B).
 	const char *tile_env = getenv("RTK_AMD_TILE_COLLAPSE_MIN");
-	const uint64_t tile_min = tile_env ? (uint64_t)atoll(tile_env) : (7ull << 19);
+	const uint64_t tile_min = tile_env ? (uint64_t)atoll(tile_env) : (3ull << 19);
 	const bool tile_mode = num_tiles > 1u && (uint64_t)n >= tile_min;
 	uint32_t *d_tile_count = ar.take<uint32_t>(num_tiles + 1u), *d_tile_base = ar.take<uint32_t>(num_tiles + 1u);
 	uint32_t *d_depth_word = ar.take<uint32_t>(4);

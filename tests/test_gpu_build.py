@@ -541,8 +541,8 @@ print("OK", int(gm.sum()), c["content_hash"])
 @pytest.mark.parametrize("n", [1025, 10_000, 300_000])
 def test_tile_local_collapse_at_small_sizes(api, oracle, n, monkeypatch):
     """The tile-local collapse (k_count_tile / k_collapse_tile: subtrees inside a 1024-triangle refit tile are turned into
-    4-wide nodes by the tile's own workgroup, numbered in pre-order behind the nodes above the tiles) is the default from 2M
-    triangles on; RTK_AMD_TILE_COLLAPSE_MIN=0 forces it here. Structure validates (every child after its parent, exact
+    4-wide nodes by the tile's own workgroup, numbered in pre-order, the nodes above the tiles behind them) is the default from
+    1.5M triangles on; RTK_AMD_TILE_COLLAPSE_MIN=0 forces it here. Structure validates (no cycles: children after their parents inside the tiles' run of numbers and inside the run above, exact
     boxes, every triangle once), two builds are byte-identical, the level-by-level build of the same input holds the same
     triangles, and tracing is bit-identical to the oracle on the exported blob."""
     tris = synth.triangle_soup(n, 0.05, seed=70)
