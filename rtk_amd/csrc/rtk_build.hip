@@ -1555,12 +1555,7 @@ __global__ void __launch_bounds__(256) k_top_finish(const DevNode *top, const ui
 		}
 		child_order(nd, nd.order);
 		if (i == 0u) {
-			float b = 0.0f;
-			for (int k = 0; k < 4; k++) {
-				if (nd.child[k] == RTK_REF_NONE) continue;
-				const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
-				for (int c = 0; c < 6; c++) b = (fabsf(v[c]) <= 3.0e38f) ? fmaxf(b, fabsf(v[c])) : INFINITY;   // NaN / inf planes: no bound
-			}
+			const float b = root_bound(nd, 0.0f);
 			consts->bound_raw = b;
 			consts->bound_abs = fmaxf(b, 1.0f);
 		}

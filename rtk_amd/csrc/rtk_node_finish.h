@@ -109,3 +109,16 @@ __device__ __forceinline__ bool quantize_node(const DevNode &nd, DevNodeQ &q)
 	for (int k = 0; k < 4; k++) q.child[k] = nd.child[k];
 	return !misfit;
 }
+
+// The scene bound from the root node (every box of a tree the device builds lies inside the root's child boxes): the largest
+// absolute plane, INFINITY if one is not finite. bound_hint: a bound the caller already knows (uploads), 0 = none.
+__device__ __forceinline__ float root_bound(const DevNode &nd, float bound_hint)
+{
+	float b = bound_hint;
+	for (int k = 0; k < 4; k++) {
+		if (nd.child[k] == RTK_REF_NONE) continue;
+		const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
+		for (int c = 0; c < 6; c++) b = (fabsf(v[c]) <= 3.0e38f) ? fmaxf(b, fabsf(v[c])) : INFINITY;   // NaN / inf planes: no bound
+	}
+	return b;
+}

@@ -18,12 +18,7 @@ __global__ void k_quantize(DevNode *nodes, uint32_t n, DevNodeQ *out, DevNode *c
 	else *reinterpret_cast<uint4 *>(nodes[i].order) = make_uint4(nd.order[0], nd.order[1], nd.order[2], nd.order[3]);
 	if (i == 0u) {
 		// every box of a tree the device builds lies inside the root's (exact unions); an upload passes the bound over all nodes
-		float b = bound_hint;
-		for (int k = 0; k < 4; k++) {
-			if (nd.child[k] == RTK_REF_NONE) continue;
-			const float v[6] = { nd.bx[0][k], nd.bx[1][k], nd.by[0][k], nd.by[1][k], nd.bz[0][k], nd.bz[1][k] };
-			for (int c = 0; c < 6; c++) b = (fabsf(v[c]) <= 3.0e38f) ? fmaxf(b, fabsf(v[c])) : INFINITY;   // NaN / inf planes: no bound
-		}
+		const float b = root_bound(nd, bound_hint);
 		consts->bound_raw = b;
 		consts->bound_abs = fmaxf(b, 1.0f);
 	}
