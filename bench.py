@@ -587,6 +587,7 @@ def main():
     # ---- the same frame WITHOUT the image hint (opts = NULL, what a host that only knows rays and records passes): the library looks
     # at the batch (two small launches and a wait per call), finds the image and runs the same kernels; records must be the same bytes
     no_hint = None
+    any_image = None
     if packet_kernel and world == 1 and args.steps:
         ref_out = d_outs[(args.steps - 1) % len(d_outs)].clone()
         k2 = max(3, args.steps // 4)
@@ -606,6 +607,25 @@ def main():
                    "records_identical_to_the_hinted_run": bool(torch.equal(ref_out, d_outs[0])),
                    "what": "rtk_dev_trace_rays(opts = NULL) on the same rays: the image is detected per call (k_detect_row, k_detect_check, one stream wait)"}
         d_outs[(args.steps - 1) % len(d_outs)].copy_(ref_out)
+        # ... and the same rays as an ANY-HIT batch with the hint (rtk_dev_trace_rays_any: one flag per ray): answered by the same
+        # packet kernels (records into a stream-ordered temporary, one pass to flags; no early exit per ray)
+        any_image = None
+        try:
+            d_flags = torch.empty(n, dtype=torch.uint8, device=dev)
+            ds.trace_any_device(d_rays, n, d_flags, opts)
+            sync()
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                ds.trace_any_device(d_rays, n, d_flags, opts)
+            sync()
+            dt2 = time.perf_counter() - t2
+            want = ref_out.view(torch.int32).view(-1, 4)[:, 3] != -1
+            any_image = {"value": round(n * k2 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
+                         "flags_equal_closest_hit_exists": bool(torch.equal(d_flags != 0, want)),
+                         "what": "rtk_dev_trace_rays_any with the image hint on the same rays: closest-hit packet kernels + k_records_to_flags"}
+            del d_flags
+        except Exception as e:      # (kept out of the headline's way)
+            any_image = {"error": repr(e)}
         del ref_out
     other_modes = {}
     if world > 1:
@@ -703,6 +723,7 @@ def main():
                                                      for how in ("striped", "root") if (how == mode or how in other_modes)}
                                                     if (world > 1 and elapsed_no_gather) else None),
                    "without_image_hint": no_hint,
+                   "any_hit_on_the_same_image": any_image,
                    "launch": "static" if args.static else "persistent",
                    "ray_order": "RTK_TRACE_SORT_RAYS: re-ordered by origin cell inside every timed step" if args.sort_rays else "as given",
                    "parallelism": "ray-batch shards x%d, BVH replicated" % world},

@@ -1064,6 +1064,18 @@ int rtk_detect_image(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	return RTK_AMD_OK;
 }
 
+// "Is there a hit" from closest-hit records, four rays per thread (one word of flags)
+__global__ void k_records_to_flags(const rtk_hit_record *rec, size_t n, uint8_t *occluded)
+{
+	const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+	if (i4 >= n) return;
+	uint32_t w = 0u;
+	const size_t left = n - i4 < 4u ? n - i4 : 4u;
+	for (size_t k = 0; k < left; k++) w |= (rec[i4 + k].prim != RTK_PRIM_NONE ? 1u : 0u) << (8u * (uint32_t)k);
+	if (left == 4u && (reinterpret_cast<uintptr_t>(occluded + i4) & 3u) == 0u) *reinterpret_cast<uint32_t *>(occluded + i4) = w;
+	else for (size_t k = 0; k < left; k++) occluded[i4 + k] = (uint8_t)((w >> (8u * (uint32_t)k)) & 1u);
+}
+
 int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
 	const rtk_dev_filter *filter, rtk_hit_record *d_cand, uint32_t *d_cand_count, uint32_t cand_k, rtk_packet_counters *pk_counted)
@@ -1075,6 +1087,26 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (collect && (!d_cand_count || cand_k == 0 || any_hit || counted)) { rtk_set_error("rtk_dev_trace: bad collect arguments"); return RTK_AMD_ERR_BAD_ARG; }
 	if (!ds || (!d_rays && n) || (!collect && (any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
+	// Any-hit on an IMAGE (the caller says so: whole 64x64-pixel blocks): "is there a hit in (min_t, max_t)" is exactly what the
+	// closest-hit packet kernels answer, at several times the rate of a ray per lane on rays that run side by side -- coherent
+	// shadow or visibility rays. The records go to a stream-ordered temporary, one small pass turns them into flags. (No early
+	// exit per ray: a pair of tiles is done when its last ray is; RTK_AMD_ANY_PACKETS=0 keeps such batches on the per-lane kernel.)
+	static const int any_packets_default = getenv("RTK_AMD_ANY_PACKETS") ? atoi(getenv("RTK_AMD_ANY_PACKETS")) : 1;
+	if (any_hit && any_packets_default != 0 && !filter && !collect && !counted && !pk_counted && d_occluded && opts && opts->struct_size >= 16 &&
+		opts->image_width >= 128u && (opts->image_width % 64u) == 0u && (opts->image_height % 64u) == 0u && (size_t)opts->image_width * opts->image_height == n &&
+		ds && ds->stack_entries <= 64 && !(opts->flags & (RTK_TRACE_NO_PACKET | RTK_TRACE_SORT_RAYS | RTK_TRACE_STATIC | RTK_TRACE_NO_ASM))) {
+		rtk_hit_record *tmp = nullptr;
+		if (hipMallocAsync(reinterpret_cast<void **>(&tmp), n * sizeof(rtk_hit_record), stream) == hipSuccess) {
+			int rc = rtk_launch_trace(ds_c, d_rays, n, tmp, nullptr, opts, stream, false, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
+			if (rc == RTK_AMD_OK) {
+				hipLaunchKernelGGL(k_records_to_flags, dim3((unsigned)((n / 4u + 255u) / 256u + 1u)), dim3(256), 0, stream, tmp, n, d_occluded);
+				if (hipGetLastError() != hipSuccess) { rtk_set_error("rtk_dev_trace: k_records_to_flags launch failed"); rc = RTK_AMD_ERR_HIP; }
+			}
+			(void)hipFreeAsync(tmp, stream);
+			return rc;
+		}
+		(void)hipGetLastError();             // (no memory for the records: the per-lane kernel needs none)
+	}
 	{
 		// the scene's memory, its scratch and `stream` must all belong to the device this thread has current: a launch from a
 		// thread on another GPU would read the scene across devices (a fault without peer access)

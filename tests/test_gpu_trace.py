@@ -311,6 +311,25 @@ def test_an_image_is_recognised_without_the_hint(api, scene1):
     assert ds.trace(inc, full=False).tobytes() == ds.trace(inc, opts=api.make_opts(no_detect=True), full=False).tobytes()
 
 
+def test_any_hit_on_an_image_takes_the_packet_kernels(api, scene2):
+    """rtk_dev_trace_rays_any with an image hint (whole 64 x 64 blocks): "is there a hit in (min_t, max_t)" is answered by the
+    closest-hit packet kernels (records into a stream-ordered temporary, one pass to flags) -- the same flags as the per-lane
+    any-hit kernel without the hint and as the closest-hit records, with bounded intervals that cut the
+    scene (max_t inside it, min_t behind the first surface)."""
+    _, ds = scene2
+    frame = synth.rays_pinhole(512, 256)
+    frame["max_t"] = np.float32(2.2)                                   # the camera is 1.5 in front of the unit cube: ends inside it
+    frame["min_t"][::3] = np.float32(1.9)
+    opts = api.make_opts(image=(512, 256))
+    occ_packets = ds.trace_any(frame, opts=opts)
+    occ_lanes = ds.trace_any(frame)
+    rec = ds.trace(frame, opts=opts, full=False)
+    assert 0.2 < occ_packets.mean() < 0.95
+    assert (occ_packets == occ_lanes).all() and (occ_packets == (rec["prim"] != 0xFFFFFFFF)).all()
+    ragged = synth.rays_pinhole(200, 96)                               # not whole blocks: per lane, same answers as closest hit
+    assert (ds.trace_any(ragged, opts=api.make_opts(image=(200, 96))) == (ds.trace(ragged, full=False)["prim"] != 0xFFFFFFFF)).all()
+
+
 def test_the_references_leaf_sizes_stay_on_the_hand_written_kernels(api, oracle, scene2):
     """The oracle's SAH builder makes leaves of 4 to 63 triangles like the reference's (rtk.c:6-7). Their full groups of four take the
     float edge functions in rtk_packet_beam2 and rtk_lane_hot_closest (the padded last group double precision), so such scenes --
