@@ -607,8 +607,8 @@ def main():
                    "records_identical_to_the_hinted_run": bool(torch.equal(ref_out, d_outs[0])),
                    "what": "rtk_dev_trace_rays(opts = NULL) on the same rays: the image is detected per call (k_detect_row, k_detect_check, one stream wait)"}
         d_outs[(args.steps - 1) % len(d_outs)].copy_(ref_out)
-        # ... and the same rays as an ANY-HIT batch with the hint (rtk_dev_trace_rays_any: one flag per ray): answered by the same
-        # packet kernels (records into a stream-ordered temporary, one pass to flags; no early exit per ray)
+        # ... and the same rays as an ANY-HIT batch with the hint (rtk_dev_trace_rays_any: one flag per ray): rtk_packet_any2, the
+        # any-hit form of the same kernel (a ray is retired at its first hit, a pair of tiles ends when every ray has its answer)
         any_image = None
         try:
             d_flags = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -622,7 +622,7 @@ def main():
             want = ref_out.view(torch.int32).view(-1, 4)[:, 3] != -1
             any_image = {"value": round(n * k2 / dt2 / 1e6, 2), "unit": "Mrays/s", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
                          "flags_equal_closest_hit_exists": bool(torch.equal(d_flags != 0, want)),
-                         "what": "rtk_dev_trace_rays_any with the image hint on the same rays: closest-hit packet kernels + k_records_to_flags"}
+                         "what": "rtk_dev_trace_rays_any with the image hint on the same rays: rtk_packet_any2 (rtk_packet_beam2.S -DRTK_ANY), flags written by the kernel"}
             del d_flags
         except Exception as e:      # (kept out of the headline's way)
             any_image = {"error": repr(e)}

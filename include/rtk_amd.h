@@ -175,9 +175,9 @@ void rtk_amd_release_workspace(void);
  * the stream (reference: rtk_trace_ray is a pure function of a const scene, rtk.c:543-577). */
 int rtk_dev_trace_rays(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	rtk_hit_record *d_hits, const rtk_trace_opts *opts, void *stream);
-/* (any-hit with an image hint of whole 64x64-pixel blocks, image_width >= 128: answered by the closest-hit packet kernels --
- * records into a stream-ordered temporary, one pass to flags -- the same flags at several times the per-lane rate on rays that
- * run side by side; other shapes ignore the hint) */
+/* (any-hit with an image hint of whole 64x64-pixel blocks, image_width >= 128: traced by the packet kernels in their any-hit form
+ * -- a ray is retired at its first hit -- the same flags at about three times the per-lane rate on rays that run side by side;
+ * other shapes ignore the hint) */
 int rtk_dev_trace_rays_any(const rtk_dev_scene *ds, const rtk_ray *d_rays, size_t n,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, void *stream);
 int rtk_dev_expand_hits(const rtk_dev_scene *ds, const rtk_hit_record *d_records, size_t n,

@@ -1064,18 +1064,6 @@ int rtk_detect_image(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	return RTK_AMD_OK;
 }
 
-// "Is there a hit" from closest-hit records, four rays per thread (one word of flags)
-__global__ void k_records_to_flags(const rtk_hit_record *rec, size_t n, uint8_t *occluded)
-{
-	const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4u;
-	if (i4 >= n) return;
-	uint32_t w = 0u;
-	const size_t left = n - i4 < 4u ? n - i4 : 4u;
-	for (size_t k = 0; k < left; k++) w |= (rec[i4 + k].prim != RTK_PRIM_NONE ? 1u : 0u) << (8u * (uint32_t)k);
-	if (left == 4u && (reinterpret_cast<uintptr_t>(occluded + i4) & 3u) == 0u) *reinterpret_cast<uint32_t *>(occluded + i4) = w;
-	else for (size_t k = 0; k < left; k++) occluded[i4 + k] = (uint8_t)((w >> (8u * (uint32_t)k)) & 1u);
-}
-
 int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n, rtk_hit_record *d_hits,
 	uint8_t *d_occluded, const rtk_trace_opts *opts, hipStream_t stream, bool any_hit, rtk_trace_counters *counted,
 	const rtk_dev_filter *filter, rtk_hit_record *d_cand, uint32_t *d_cand_count, uint32_t cand_k, rtk_packet_counters *pk_counted)
@@ -1087,26 +1075,6 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (collect && (!d_cand_count || cand_k == 0 || any_hit || counted)) { rtk_set_error("rtk_dev_trace: bad collect arguments"); return RTK_AMD_ERR_BAD_ARG; }
 	if (!ds || (!d_rays && n) || (!collect && (any_hit ? !d_occluded : !d_hits) && n)) { rtk_set_error("rtk_dev_trace: bad argument"); return RTK_AMD_ERR_BAD_ARG; }
 	if (n == 0) { if (counted) *counted = rtk_trace_counters(); return RTK_AMD_OK; }
-	// Any-hit on an IMAGE (the caller says so: whole 64x64-pixel blocks): "is there a hit in (min_t, max_t)" is exactly what the
-	// closest-hit packet kernels answer, at several times the rate of a ray per lane on rays that run side by side -- coherent
-	// shadow or visibility rays. The records go to a stream-ordered temporary, one small pass turns them into flags. (No early
-	// exit per ray: a pair of tiles is done when its last ray is; RTK_AMD_ANY_PACKETS=0 keeps such batches on the per-lane kernel.)
-	static const int any_packets_default = getenv("RTK_AMD_ANY_PACKETS") ? atoi(getenv("RTK_AMD_ANY_PACKETS")) : 1;
-	if (any_hit && any_packets_default != 0 && !filter && !collect && !counted && !pk_counted && d_occluded && opts && opts->struct_size >= 16 &&
-		opts->image_width >= 128u && (opts->image_width % 64u) == 0u && (opts->image_height % 64u) == 0u && (size_t)opts->image_width * opts->image_height == n &&
-		ds && ds->stack_entries <= 64 && !(opts->flags & (RTK_TRACE_NO_PACKET | RTK_TRACE_SORT_RAYS | RTK_TRACE_STATIC | RTK_TRACE_NO_ASM))) {
-		rtk_hit_record *tmp = nullptr;
-		if (hipMallocAsync(reinterpret_cast<void **>(&tmp), n * sizeof(rtk_hit_record), stream) == hipSuccess) {
-			int rc = rtk_launch_trace(ds_c, d_rays, n, tmp, nullptr, opts, stream, false, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
-			if (rc == RTK_AMD_OK) {
-				hipLaunchKernelGGL(k_records_to_flags, dim3((unsigned)((n / 4u + 255u) / 256u + 1u)), dim3(256), 0, stream, tmp, n, d_occluded);
-				if (hipGetLastError() != hipSuccess) { rtk_set_error("rtk_dev_trace: k_records_to_flags launch failed"); rc = RTK_AMD_ERR_HIP; }
-			}
-			(void)hipFreeAsync(tmp, stream);
-			return rc;
-		}
-		(void)hipGetLastError();             // (no memory for the records: the per-lane kernel needs none)
-	}
 	{
 		// the scene's memory, its scratch and `stream` must all belong to the device this thread has current: a launch from a
 		// thread on another GPU would read the scene across devices (a fault without peer access)
@@ -1182,8 +1150,14 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		filtered = p.mesh_mask || p.ignore_prim || p.after;
 	}
 
-	// image-shaped closest-hit batches go to the wave-packet kernel (rtk_trace_packet.hip)
-	const bool packet = !any_hit && !filtered && !collect && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
+	// image-shaped closest-hit batches go to the wave-packet kernels (rtk_trace_packet.hip). So do image-shaped ANY-HIT batches of
+	// whole 64x64-pixel blocks: "is there a hit in (min_t, max_t)" is what a closest-hit traversal answers, at several times the rate of
+	// a ray per lane where the rays run side by side (coherent shadow / visibility rays); rtk_packet_any2 retires a ray at its first
+	// hit and writes the flags, the C++ kernel (the tiles handed back) writes "the closest hit exists". RTK_AMD_ANY_PACKETS=0: per lane.
+	static const int any_packets_default = getenv("RTK_AMD_ANY_PACKETS") ? atoi(getenv("RTK_AMD_ANY_PACKETS")) : 1;
+	const bool any_packet = any_hit && any_packets_default != 0 && !counted && p.image_w >= 128u && (p.image_w % 64u) == 0u && (p.image_h % 64u) == 0u &&
+		!(opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_SORT_RAYS | RTK_TRACE_STATIC)));
+	const bool packet = (!any_hit || any_packet) && !filtered && !collect && p.image_w != 0 && ds->stack_entries <= 64 && !(opts && (opts->flags & RTK_TRACE_NO_PACKET));
 	// per-lane kernels read the 64 B compressed nodes unless told otherwise (A/B, and tests that compare the two)
 	static const int qnodes_default = getenv("RTK_AMD_QNODES") ? atoi(getenv("RTK_AMD_QNODES")) : 1;
 	const bool qn = ds->view.qnodes != nullptr && qnodes_default != 0 && !(opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_EXACT_NODES));
@@ -1199,12 +1173,13 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 	if (opts && opts->struct_size >= 16 && (opts->flags & RTK_TRACE_ONE_TILE_BEAM) && beam == 2) beam = 1;
 	while (beam > 0 && !rtk_packet_hot_available(ds->device, nullptr, beam)) beam--;
 	// the counting form of the kernel that is timed (rtk_packet_count2 = rtk_packet_beam2.S with -DRTK_COUNT): only where that kernel runs
+	if (any_hit && packet) beam = (beam == 2 && rtk_packet_hot_available(ds->device, nullptr, 4)) ? 4 : -1;     // (the any-hit form exists of rtk_packet_beam2 only; -1: the C++ kernel)
 	if (pk_counted) {
 		if (beam != 2 || !rtk_packet_hot_available(ds->device, nullptr, 3)) { rtk_set_error("rtk_dev_trace_rays_packet_counted: rtk_packet_beam2 is not the kernel of this launch"); return RTK_AMD_ERR_UNSUPPORTED; }
 		beam = 3;
 	}
 	int hot_blocks_per_cu = 0;
-	const bool hot = packet && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
+	const bool hot = packet && beam >= 0 && !counted && asm_default != 0 && p.tile_blocks && p.image_w >= 128u && p.image_w <= 65536u && n <= 0x40000000ull &&
 		ds->bound_abs < 0x1p19f && (beam >= 2 || ds->big_leaf_fraction <= 0.02) && !(opts && (opts->flags & RTK_TRACE_NO_ASM)) &&
 		rtk_packet_hot_available(ds->device, &hot_blocks_per_cu, beam);       // (rtk_packet_beam2 has the group rule for leaves of four and more triangles; the one-tile kernels hand such tiles back)
 	if (pk_counted && !hot) { rtk_set_error("rtk_dev_trace_rays_packet_counted: this batch does not run on the assembly packet kernel (image hint, whole 64x64-pixel blocks, small leaves)"); return RTK_AMD_ERR_UNSUPPORTED; }
@@ -1319,7 +1294,7 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 			sc->leftover_capacity = tiles;
 		}
 		PkHotParams hp = {};
-		hp.nodes = p.sc.nodes; hp.tris = p.sc.tris; hp.rays = p.rays; hp.hits = p.hits; hp.counter = p.counter; hp.leftover = sc->d_leftover;
+		hp.nodes = p.sc.nodes; hp.tris = p.sc.tris; hp.rays = p.rays; hp.hits = any_hit ? reinterpret_cast<rtk_hit_record *>(p.occluded) : p.hits; hp.counter = p.counter; hp.leftover = sc->d_leftover;
 		hp.num_blocks = (uint32_t)(tiles >> 6);
 		hp.image_w = p.image_w;
 		hp.blocks_per_row = p.image_w >> 6;

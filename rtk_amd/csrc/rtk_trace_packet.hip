@@ -621,9 +621,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK_THREADS, PK_MIN_WAVES) rtk_trace_p
 
 		if (overflow && lane == 0) p.counter[RTK_ERROR_WORD] = 1ull;
 		if (alive) {
-			f32x4 rec;
-			rec.x = L.t; rec.y = L.u; rec.z = L.v; rec.w = __uint_as_float(L.prim);
-			__builtin_nontemporal_store(rec, reinterpret_cast<f32x4 *>(p.hits + ray_index));
+			if (p.occluded) p.occluded[ray_index] = L.prim != RTK_PRIM_NONE ? 1 : 0;       // an any-hit batch on an image: "the closest hit exists"
+			else {
+				f32x4 rec;
+				rec.x = L.t; rec.y = L.u; rec.z = L.v; rec.w = __uint_as_float(L.prim);
+				__builtin_nontemporal_store(rec, reinterpret_cast<f32x4 *>(p.hits + ray_index));
+			}
 			if (COUNT) {
 				atomicAdd(p.counter + 1, 1ull);
 				atomicAdd(p.counter + 2, (unsigned long long)c_nodes);
@@ -806,7 +809,7 @@ void rtk_packet_entries_launch(const TraceParams &p, PkBlockEntries *out, float 
 #include <mutex>
 
 namespace {
-struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_beam = nullptr, fn_beam2 = nullptr, fn_count2 = nullptr; int blocks_per_cu = 0, beam_blocks_per_cu = 0, beam2_blocks_per_cu = 0; bool tried = false; };
+struct HotModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_beam = nullptr, fn_beam2 = nullptr, fn_count2 = nullptr, fn_any2 = nullptr; int blocks_per_cu = 0, beam_blocks_per_cu = 0, beam2_blocks_per_cu = 0; bool tried = false; };
 std::mutex g_hot_mutex;
 HotModule g_hot[RTK_MAX_DEVICES];
 
@@ -844,6 +847,8 @@ HotModule *hot_module(int device)
 			}
 			// rtk_packet_count2: rtk_packet_beam2.S assembled with -DRTK_COUNT (the counting form of the kernel that is timed)
 			if (hipModuleGetFunction(&h.fn_count2, h.mod, "rtk_packet_count2") != hipSuccess) { (void)hipGetLastError(); h.fn_count2 = nullptr; }
+			// rtk_packet_any2: ... with -DRTK_ANY (one flag per ray, a ray retired at its first hit)
+			if (hipModuleGetFunction(&h.fn_any2, h.mod, "rtk_packet_any2") != hipSuccess) { (void)hipGetLastError(); h.fn_any2 = nullptr; }
 		}
 	}
 	return h.fn ? &h : nullptr;
@@ -853,7 +858,7 @@ HotModule *hot_module(int device)
 bool rtk_packet_hot_available(int device, int *blocks_per_cu, int beam)
 {
 	HotModule *h = hot_module(device);
-	if (!h || (beam == 1 && !h->fn_beam) || (beam == 2 && !h->fn_beam2) || (beam == 3 && !h->fn_count2)) return false;
+	if (!h || (beam == 1 && !h->fn_beam) || (beam == 2 && !h->fn_beam2) || (beam == 3 && !h->fn_count2) || (beam == 4 && !h->fn_any2)) return false;
 	if (blocks_per_cu) *blocks_per_cu = beam >= 2 ? h->beam2_blocks_per_cu : beam == 1 ? h->beam_blocks_per_cu : h->blocks_per_cu;
 	return true;
 }
@@ -861,11 +866,11 @@ bool rtk_packet_hot_available(int device, int *blocks_per_cu, int beam)
 int rtk_packet_hot_launch(int device, const PkHotParams &hp_in, unsigned blocks, hipStream_t stream, int beam)
 {
 	HotModule *h = hot_module(device);
-	if (!h || (beam == 1 && !h->fn_beam) || (beam == 2 && !h->fn_beam2) || (beam == 3 && !h->fn_count2)) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
+	if (!h || (beam == 1 && !h->fn_beam) || (beam == 2 && !h->fn_beam2) || (beam == 3 && !h->fn_count2) || (beam == 4 && !h->fn_any2)) { rtk_set_error("rtk_dev_trace: the assembly packet kernel is not loaded"); return RTK_AMD_ERR_HIP; }
 	PkHotParams hp = hp_in;
 	size_t size = sizeof(hp);
 	void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &hp, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
-	RTK_HIP_CHECK(hipModuleLaunchKernel(beam == 3 ? h->fn_count2 : beam == 2 ? h->fn_beam2 : beam == 1 ? h->fn_beam : h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
+	RTK_HIP_CHECK(hipModuleLaunchKernel(beam == 4 ? h->fn_any2 : beam == 3 ? h->fn_count2 : beam == 2 ? h->fn_beam2 : beam == 1 ? h->fn_beam : h->fn, blocks, 1, 1, TRACE_BLOCK_THREADS, 1, 1, 0, stream, nullptr, config), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
 }
 

@@ -341,3 +341,56 @@ def test_leaves_of_four_and_more_triangles_follow_the_group_rule(oracle):
     res1, left1, _ = run_packet_kernel("rtk_packet_beam", nodes, tr, rays, W, H, workgroups=1)
     done1 = check(res1, left1, g_hits, g_mask, rays, W, H)
     assert done1.mean() < done.mean()
+
+
+def run_any_kernel(nodes, tr, rays, w, h, entries=None, workgroups=2):
+    """rtk_packet_any2 (rtk_packet_beam2.S with -DRTK_ANY): the same arguments, the hits pointer is the flags', one byte per ray"""
+    mem = emu.Memory()
+    n = w * h
+    a_n, a_t, a_r = mem.add("nodes", nodes), mem.add("tris", tr), mem.add("rays", rays)
+    a_o = mem.add("flags", np.full(n, 0x7e, dtype=np.uint8))
+    a_c = mem.add("counter", np.zeros(COUNTER_WORDS, dtype=np.uint64))
+    a_l = mem.add("leftover", np.zeros(n // 64, dtype=np.uint32))
+    a_e = mem.add("entries", entries) if entries is not None else 0
+    bound = max(1.0, float(np.abs(tr["v0"]).max()), float(np.abs(tr["v1"]).max()), float(np.abs(tr["v2"]).max()))
+    bpr = w // 64
+    karg = struct.pack("<6Q4IfIQ", a_n, a_t, a_r, a_o, a_c, a_l, (w // 64) * (h // 64), w, bpr, (0x100000000 + bpr - 1) // bpr, bound, 0, a_e)
+    stats = emu.run_kernel(os.path.join(CSRC, "obj", "rtk_packet_any2.o"), "rtk_packet_any2", mem, karg, workgroups, 0, max_instructions=6_000_000)
+    flags = mem.get(a_o).view(np.uint8).copy()
+    counter = mem.get(a_c).view(np.uint64)
+    left = mem.get(a_l).view(np.uint32)[:int(counter[10])].copy()
+    return flags, left, stats
+
+
+def test_the_any_hit_form_retires_rays_at_their_first_hit(oracle, scene):
+    """rtk_packet_any2: one flag per ray = "the closest hit exists" (the oracle's mask), for unbounded rays, for rays that end inside
+    the scene and for rays that start behind its first surfaces; tiles it hands back are untouched. A ray is retired at its first
+    accepted hit and a pair ends when every ray has its answer: never more work than the closest-hit kernel."""
+    subprocess.check_call(["make", "-s", "-C", CSRC, os.path.join(os.path.abspath(CSRC), "obj", "rtk_packet_hot.hsaco")])
+    tv, tr, nodes = scene
+    tiles = tile_of_pixels(W, H)
+    total = {}
+    for name, lo, hi in (("unbounded", 0.0, 3.0e38), ("ends inside", 0.0, 2.0), ("starts inside", 1.9, 3.0e38)):
+        rays = camera(0.02, 0.05, 0.55)
+        rays["min_t"] = np.float32(lo)
+        rays["max_t"] = np.float32(hi)
+        _, g_mask = chain_oracle(oracle, tv, rays)
+        assert 0.03 < g_mask.mean() < 0.98, name
+        flags, left, st = run_any_kernel(nodes, tr, rays, W, H)
+        assert len(left) == 0
+        assert (flags == g_mask.astype(np.uint8)).all(), name
+        ent = beam_entries(nodes, rays, W, H, bound=2.0, target=12)
+        flags_e, left, _ = run_any_kernel(nodes, tr, rays, W, H, entries=ent)
+        assert len(left) == 0 and (flags_e == flags).all(), name
+        total[name] = sum(s["total"] for s in st)
+    rays = camera(0.02, 0.05, 0.55)
+    _, _, st_closest = run_packet_kernel("rtk_packet_beam2", nodes, tr, rays, W, H)
+    # (on this sparse scene next to no tile has an answer for all of its 64 rays before the traversal ends anyway: the same work)
+    assert total["unbounded"] < 1.03 * sum(s["total"] for s in st_closest), (total, sum(s["total"] for s in st_closest))
+    # a frame with rays of both signs: the centre tiles are handed back untouched, the others answered
+    mixed = camera(-0.25, -0.12, 0.5)
+    _, m_mask = chain_oracle(oracle, tv, mixed)
+    flags, left, _ = run_any_kernel(nodes, tr, mixed, W, H, entries=beam_entries(nodes, mixed, W, H, bound=2.0, target=12))
+    handed = np.isin(tiles, left)
+    assert 0 < handed.sum() < len(handed)
+    assert (flags[handed] == 0x7e).all() and (flags[~handed] == m_mask[~handed].astype(np.uint8)).all()
