@@ -1121,11 +1121,11 @@ int rtk_launch_trace(const rtk_dev_scene *ds_c, const rtk_ray *d_rays, size_t n,
 		}
 		if (opts->struct_size >= 28 && opts->node_exit) p.node_exit = opts->node_exit > 64 ? 64 : opts->node_exit;
 	}
-	// No image hint: is the batch an image anyway? Only worth asking where the packet kernels would take it (a closest-hit batch
-	// without filters, whole 64x64-pixel blocks); costs two small launches and one wait for `stream` (~20 us; the wait also
+	// No image hint: is the batch an image anyway? Only worth asking where the packet kernels would take it (a closest-hit or any-hit
+	// batch without filters, whole 64x64-pixel blocks); costs two small launches and one wait for `stream` (~20 us; the wait also
 	// stands between this batch and the host's next enqueue: a caller that knows its image says so in the options).
 	static const int detect_default = getenv("RTK_AMD_DETECT_IMAGE") ? atoi(getenv("RTK_AMD_DETECT_IMAGE")) : 1;
-	if (detect_default != 0 && p.image_w == 0 && !any_hit && !filter && !collect && !counted && !pk_counted && n >= 16384u && (n % 4096u) == 0u && n <= 0x40000000ull &&
+	if (detect_default != 0 && p.image_w == 0 && !filter && !collect && !counted && !pk_counted && n >= 16384u && (n % 4096u) == 0u && n <= 0x40000000ull &&
 		p.dynamic && ds->stack_entries <= 64 && !(opts && opts->struct_size >= 16 && (opts->flags & (RTK_TRACE_NO_DETECT | RTK_TRACE_NO_PACKET | RTK_TRACE_SORT_RAYS | RTK_TRACE_STATIC)))) {
 		uint32_t w = 0, h = 0;
 		const int rc = rtk_detect_image(ds, d_rays, n, stream, &w, &h);

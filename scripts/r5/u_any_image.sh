@@ -11,7 +11,7 @@ frame["max_t"] = np.float32(2.2)
 n = len(frame)
 d_rays = api.to_device(frame)
 d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
-for name, opts in (("image hint (packet kernels)", api.make_opts(image=(4096, 4096))), ("no hint (one ray per lane)", None)):
+for name, opts in (("image hint (packet kernels)", api.make_opts(image=(4096, 4096))), ("no hint, no look (one ray per lane)", api.make_opts(no_detect=True)), ("no hint (the batch is looked at)", None)):
     for _ in range(3): ds.trace_any_device(d_rays, n, d_occ, opts)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): ds.trace_any_device(d_rays, n, d_occ, opts)

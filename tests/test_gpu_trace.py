@@ -322,7 +322,8 @@ def test_any_hit_on_an_image_takes_the_packet_kernels(api, scene2):
     frame["min_t"][::3] = np.float32(1.9)
     opts = api.make_opts(image=(512, 256))
     occ_packets = ds.trace_any(frame, opts=opts)
-    occ_lanes = ds.trace_any(frame)
+    occ_lanes = ds.trace_any(frame, opts=api.make_opts(no_detect=True))      # (without the hint the batch would be recognised as an image)
+    assert (ds.trace_any(frame) == occ_packets).all()
     rec = ds.trace(frame, opts=opts, full=False)
     assert 0.2 < occ_packets.mean() < 0.95
     assert (occ_packets == occ_lanes).all() and (occ_packets == (rec["prim"] != 0xFFFFFFFF)).all()
