@@ -447,20 +447,26 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sort_scatter(const unsigned long
 // triangle i at pos + (3 i + c) * stride), or the staged records (pos == NULL)
 struct MeshSrc { const char *pos; unsigned long long stride; };
 
-__global__ void k_emit_tris(const InTri *in_tris, const MeshSrc *src, const uint32_t *vals, const unsigned long long *words, uint32_t n,
-	const unsigned long long *mesh_base, uint32_t num_meshes, DevTri *tris)
+struct EmitSrc {
+	const InTri *in_tris;                 // staged records (meshes that are not read in place)
+	const MeshSrc *src;                   // per mesh: where its positions are read from
+	const uint32_t *vals;                 // sorted order: triangle numbers (pairs), or NULL:
+	const unsigned long long *words;      // packed sort words, the number in their low 24 bits
+	const unsigned long long *mesh_base;
+	uint32_t num_meshes;
+};
+
+// the record of sorted triangle s: its positions gathered from the caller's position buffer (implicit float meshes) or the staged records
+__device__ __forceinline__ DevTri make_tri(const EmitSrc &e, uint32_t s)
 {
-	const uint32_t s_own = blockIdx.x * blockDim.x + threadIdx.x;
-	if ((s_own & ~63u) >= n) return;                                            // (whole waves only: the stores below are shared by the wave)
-	const uint32_t s = s_own < n ? s_own : n - 1u;                              // (lanes behind the last triangle make a copy of it that is not written)
-	const uint32_t g = vals ? vals[s] : (uint32_t)(words[s] & 0xffffffull);     // packed sort words carry the index in their low 24 bits
+	const uint32_t g = e.vals ? e.vals[s] : (uint32_t)(e.words[s] & 0xffffffull);     // packed sort words carry the index in their low 24 bits
 	// mesh of global primitive g: last m with mesh_base[m] <= g
-	uint32_t lo = 0, hi = num_meshes;
-	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (mesh_base[mid] <= g) lo = mid; else hi = mid; }
-	const MeshSrc ms = src[lo];
+	uint32_t lo = 0, hi = e.num_meshes;
+	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (e.mesh_base[mid] <= g) lo = mid; else hi = mid; }
+	const MeshSrc ms = e.src[lo];
 	DevTri t;
 	if (ms.pos) {
-		const size_t first = 3u * (size_t)(g - (uint32_t)mesh_base[lo]);
+		const size_t first = 3u * (size_t)(g - (uint32_t)e.mesh_base[lo]);
 		const float *p0 = reinterpret_cast<const float *>(ms.pos + first * ms.stride);
 		const float *p1 = reinterpret_cast<const float *>(ms.pos + (first + 1u) * ms.stride);
 		const float *p2 = reinterpret_cast<const float *>(ms.pos + (first + 2u) * ms.stride);
@@ -468,7 +474,7 @@ __global__ void k_emit_tris(const InTri *in_tris, const MeshSrc *src, const uint
 		t.v1[0] = p1[0]; t.v1[1] = p1[1]; t.v1[2] = p1[2];
 		t.v2[0] = p2[0]; t.v2[1] = p2[1]; t.v2[2] = p2[2];
 	} else {
-		const float4 *rec = reinterpret_cast<const float4 *>(in_tris + g);
+		const float4 *rec = reinterpret_cast<const float4 *>(e.in_tris + g);
 		const float4 a = rec[0], b = rec[1], c = rec[2];      // p0 p1 p2 p3 | p4 p5 p6 p7 | p8 vi0 vi1 vi2
 		t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z;
 		t.v1[0] = a.w; t.v1[1] = b.x; t.v1[2] = b.y;
@@ -481,42 +487,58 @@ __global__ void k_emit_tris(const InTri *in_tris, const MeshSrc *src, const uint
 	t.spare = 1u;
 #if RTK_TRI_STRIDE == 64
 	t.pad[0] = t.pad[1] = t.pad[2] = t.pad[3] = 0u;
-	if (s_own < n) tris[s] = t;
+#endif
+	return t;
+}
+
+// stores the records of one wave (lane l: sorted triangle s_own, record t; n triangles in all). Every lane of the wave takes part.
+__device__ __forceinline__ void store_tris(DevTri *tris, uint32_t s_own, uint32_t n, const DevTri &t)
+{
+#if RTK_TRI_STRIDE == 64
+	if (s_own < n) tris[s_own] = t;
 #else
 	// The wave's 64 records are 192 16-byte pieces in a row: store k writes pieces 64 k + lane, 1 KB without a gap (a record per
 	// lane is three stores of 16 bytes at a stride of 48: 64 partial lines each). Piece w of the record of lane r is number
 	// 3 r + w: it goes to lane (3 r + w) mod 64 -- one to one, 3 and 64 have no common factor -- which receives one piece for
 	// each of its three stores: the one of store k has w = (lane + k) mod 3 (64 = 1 mod 3).
-	{
-		const uint32_t lane = threadIdx.x & 63u;
-		const uint32_t piece[3][4] = {
-			{ __float_as_uint(t.v0[0]), __float_as_uint(t.v0[1]), __float_as_uint(t.v0[2]), t.prim },
-			{ __float_as_uint(t.v1[0]), __float_as_uint(t.v1[1]), __float_as_uint(t.v1[2]), t.flags },
-			{ __float_as_uint(t.v2[0]), __float_as_uint(t.v2[1]), __float_as_uint(t.v2[2]), t.spare } };
-		uint32_t got[3][4];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t piece[3][4] = {
+		{ __float_as_uint(t.v0[0]), __float_as_uint(t.v0[1]), __float_as_uint(t.v0[2]), t.prim },
+		{ __float_as_uint(t.v1[0]), __float_as_uint(t.v1[1]), __float_as_uint(t.v1[2]), t.flags },
+		{ __float_as_uint(t.v2[0]), __float_as_uint(t.v2[1]), __float_as_uint(t.v2[2]), t.spare } };
+	uint32_t got[3][4];
 #pragma unroll
-		for (uint32_t w = 0; w < 3u; w++) {
-			const int to = (int)(((3u * lane + w) & 63u) << 2);
+	for (uint32_t w = 0; w < 3u; w++) {
+		const int to = (int)(((3u * lane + w) & 63u) << 2);
 #pragma unroll
-			for (int c = 0; c < 4; c++) got[w][c] = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)piece[w][c]);
-		}
-		uint4 *out = reinterpret_cast<uint4 *>(tris + (s_own - lane));
-		const uint32_t left = n - (s_own - lane);                               // records of this wave that exist
-		const uint32_t w0 = lane % 3u;
+		for (int c = 0; c < 4; c++) got[w][c] = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)piece[w][c]);
+	}
+	if (s_own - lane >= n) return;
+	uint4 *out = reinterpret_cast<uint4 *>(tris + (s_own - lane));
+	const uint32_t left = n - (s_own - lane);                               // records of this wave that exist
+	const uint32_t w0 = lane % 3u;
 #pragma unroll
-		for (uint32_t k = 0; k < 3u; k++) {
-			const uint32_t w = (w0 + k) % 3u, m = 64u * k + lane;
-			uint4 v;
-			const uint32_t a0 = got[0][0], a1 = got[1][0], a2 = got[2][0], b0 = got[0][1], b1 = got[1][1], b2 = got[2][1];
-			const uint32_t c0 = got[0][2], c1 = got[1][2], c2 = got[2][2], d0 = got[0][3], d1 = got[1][3], d2 = got[2][3];
-			v.x = w == 0u ? a0 : (w == 1u ? a1 : a2);
-			v.y = w == 0u ? b0 : (w == 1u ? b1 : b2);
-			v.z = w == 0u ? c0 : (w == 1u ? c1 : c2);
-			v.w = w == 0u ? d0 : (w == 1u ? d1 : d2);
-			if (m / 3u < left) out[m] = v;
-		}
+	for (uint32_t k = 0; k < 3u; k++) {
+		const uint32_t w = (w0 + k) % 3u, m = 64u * k + lane;
+		uint4 v;
+		const uint32_t a0 = got[0][0], a1 = got[1][0], a2 = got[2][0], b0 = got[0][1], b1 = got[1][1], b2 = got[2][1];
+		const uint32_t c0 = got[0][2], c1 = got[1][2], c2 = got[2][2], d0 = got[0][3], d1 = got[1][3], d2 = got[2][3];
+		v.x = w == 0u ? a0 : (w == 1u ? a1 : a2);
+		v.y = w == 0u ? b0 : (w == 1u ? b1 : b2);
+		v.z = w == 0u ? c0 : (w == 1u ? c1 : c2);
+		v.w = w == 0u ? d0 : (w == 1u ? d1 : d2);
+		if (m / 3u < left) out[m] = v;
 	}
 #endif
+}
+
+// (A/B only, RTK_AMD_FUSED_EMIT=0: the records are normally made inside k_refit_tile, which needs them next)
+__global__ void k_emit_tris(EmitSrc e, uint32_t n, DevTri *tris)
+{
+	const uint32_t s_own = blockIdx.x * blockDim.x + threadIdx.x;
+	if ((s_own & ~63u) >= n) return;                                            // (whole waves only: the stores are shared by the wave)
+	const uint32_t s = s_own < n ? s_own : n - 1u;                              // (lanes behind the last triangle make a copy of it that is not written)
+	store_tris(tris, s_own, n, make_tri(e, s));
 	// (the side arrays -- original vertex indices, primitive -> slot, slot -> mesh / triangle -- were written here, 52 bytes per
 	// triangle with one scattered word: rtk_scene_side_arrays makes them when something asks for a full rtk_hit, a validation or
 	// an export, not in every build)
@@ -579,6 +601,19 @@ __device__ __forceinline__ BinNode leaf_record(const DevTri *tris, uint32_t s, c
 {
 	BinNode b;
 	tri_box(tris, s, b.mn, b.mx);
+	b.cnt_flag = 1u;
+	b.cost = bp.cost_tri * half_area(b.mn, b.mx);
+	return b;
+}
+
+__device__ __forceinline__ BinNode leaf_record_of(const DevTri &t, const BuildParams &bp)
+{
+	BinNode b;
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		b.mn[a] = fminf(fminf(t.v0[a], t.v1[a]), t.v2[a]);
+		b.mx[a] = fmaxf(fmaxf(t.v0[a], t.v1[a]), t.v2[a]);
+	}
 	b.cnt_flag = 1u;
 	b.cost = bp.cost_tri * half_area(b.mn, b.mx);
 	return b;
@@ -685,9 +720,13 @@ struct Climb { int cur_ref; int l; int r; };      // cur_ref: >= 0 inner node, <
 // (never 0: a range end is below 2^32 - 1). Which side it is the second arriver knows: the other one.
 __device__ __forceinline__ unsigned long long meet_word(int ref, int end) { return (((unsigned long long)(uint32_t)ref << 32) | (uint32_t)end) + 1ull; }
 
-__global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
+// emit.src != NULL: the kernel first MAKES the tile's triangle records (what k_emit_tris does: positions gathered in sorted order) and
+// writes them out; each thread keeps its own in registers for the leaf record. A separate pass wrote 48 bytes per triangle that this
+// one read straight back, and its gather (bound by the CU's vector memory pipe) ran apart from this kernel's climb (bound by LDS round
+// trips): side by side on a CU's two workgroups the two overlap.
+__global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(DevTri *tris, int n, const unsigned long long *keys, int2 *lr, uint2 *range,
 	BinNode *bin, Climb *climbers, unsigned long long *meet, int *climb_idx, uint32_t *tile_nclimb, int *root, BuildParams bp, float *area,
-	uint32_t *equal_codes, int *root_list, uint32_t *tile_nroots)
+	uint32_t *equal_codes, int *root_list, uint32_t *tile_nroots, EmitSrc emit)
 {
 	__shared__ uint32_t s_nclimb, s_nroot;
 	__shared__ BinNode s_bin[REFIT_TILE];      // 32 KB
@@ -698,6 +737,12 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	const int lo = (int)blockIdx.x * REFIT_TILE;
 	const int hi = (lo + REFIT_TILE < n ? lo + REFIT_TILE : n) - 1;     // last sorted triangle of the tile
 	const int t = (int)threadIdx.x;
+	DevTri mine = {};
+	if (emit.src) {
+		const uint32_t s_own = (uint32_t)(lo + t);
+		mine = make_tri(emit, s_own < (uint32_t)n ? s_own : (uint32_t)n - 1u);
+		store_tris(tris, s_own, (uint32_t)n, mine);      // (visible to the other waves of the workgroup behind the barrier below: the climb reads sibling leaves)
+	}
 	s_arrive[t] = 0u;
 	if (t == 0) { s_nclimb = 0u; s_nroot = 0u; }
 	s_lr[t] = make_int2(INT_MIN, INT_MIN);
@@ -716,7 +761,7 @@ __global__ void __launch_bounds__(REFIT_BLOCK) k_refit_tile(const DevTri *tris, 
 	Climb left_over;
 	left_over.cur_ref = INT_MIN; left_over.l = left_over.r = 0;
 	if (i <= hi) {
-		BinNode cur = leaf_record(tris, (uint32_t)i, bp);
+		BinNode cur = emit.src ? leaf_record_of(mine, bp) : leaf_record(tris, (uint32_t)i, bp);
 		int cur_ref = ~i, L = i, R = i;
 		for (;;) {
 			if (L == 0 && R == n - 1) { *root = cur_ref; break; }          // the whole scene inside one tile
@@ -2114,9 +2159,14 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	{
 		if (hipMemcpyAsync(d_mesh_base, mb.data(), mb.size() * 8, hipMemcpyHostToDevice, bs) != hipSuccess ||
 			hipMemcpyAsync(d_mesh_src, mesh_src.data(), mesh_src.size() * sizeof(MeshSrc), hipMemcpyHostToDevice, bs) != hipSuccess) return fail("copy");
-		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, bs, in_tris, d_mesh_src, vals, keys, n, d_mesh_base,
-			(uint32_t)desc->num_meshes, d_tris);
+	}
+	// the triangle records in sorted order are made by k_refit_tile, which needs them next (RTK_AMD_FUSED_EMIT=0: by a pass of their own, A/B)
+	EmitSrc emit_src = { in_tris, d_mesh_src, vals, keys, d_mesh_base, (uint32_t)desc->num_meshes };
+	const bool fused_emit = !(getenv("RTK_AMD_FUSED_EMIT") && atoi(getenv("RTK_AMD_FUSED_EMIT")) == 0);
+	if (!fused_emit) {
+		hipLaunchKernelGGL(k_emit_tris, dim3((n + 255u) / 256u), dim3(256), 0, bs, emit_src, n, d_tris);
 		if (hipGetLastError() != hipSuccess) return fail("emit launch");
+		emit_src.src = nullptr;
 	}
 	stage("emit");
 
@@ -2165,7 +2215,7 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
 	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
 		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area, d_depth_word + 1, tile_mode ? d_root_list : (int *)nullptr,
-		tile_mode ? d_tile_nroots : (uint32_t *)nullptr);
+		tile_mode ? d_tile_nroots : (uint32_t *)nullptr, emit_src);
 	bool forked = false;
 	hipStream_t cs = bs;
 	if (tile_mode) {
