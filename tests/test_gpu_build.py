@@ -586,6 +586,27 @@ def test_tile_local_collapse_at_small_sizes(api, oracle, n, monkeypatch):
                  m2, h2["mesh_index"], h2["triangle_index"], h2["t"], h2["u"], h2["v"], "tile collapse vs level collapse")
 
 
+def test_records_made_inside_the_refit_are_the_separate_pass_records(api, monkeypatch):
+    """k_refit_tile makes the triangle records of its tile itself (the gather of k_emit_tris fused in; each thread keeps its own record for
+    the leaf box). RTK_AMD_FUSED_EMIT=0 runs the separate pass: the same scene, byte for byte -- for a float mesh read in place, for
+    indexed / double / multi-mesh scenes that go through staged records, below and above the tile collapse's threshold."""
+    scenes = [[dict(positions=synth.triangle_soup(30_001, 0.05, seed=5))],
+              [dict(positions=synth.triangle_soup(2_100_000, 0.02, seed=6))]]
+    v = synth.triangle_soup(5_000, 0.05, seed=7).reshape(-1, 3)
+    idx = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)[::-1].copy()
+    scenes.append([dict(positions=v, indices=idx), dict(positions=synth.triangle_soup(3_000, 0.05, seed=8).astype(np.float64))])
+    for meshes in scenes:
+        monkeypatch.delenv("RTK_AMD_FUSED_EMIT", raising=False)
+        fused = api.DeviceScene.build(meshes)
+        ok, c = fused.validate()
+        assert ok, c
+        monkeypatch.setenv("RTK_AMD_FUSED_EMIT", "0")
+        apart = api.DeviceScene.build(meshes)
+        assert apart.validate()[1]["content_hash"] == c["content_hash"]
+        assert apart.export_blob().tobytes() == fused.export_blob().tobytes()
+    monkeypatch.delenv("RTK_AMD_FUSED_EMIT", raising=False)
+
+
 def test_clustered_scene_is_rebuilt_with_wide_keys(api, oracle, monkeypatch):
     """The Morton key width follows the number of triangles (32 bits at 200k), which is too narrow when they sit in 1 % of the
     scene box: dozens share a cell and are ordered by their numbers. k_refit_tile counts equal-code neighbours and the build is
