@@ -954,6 +954,23 @@ struct LevelState {
 	uint32_t pad[3];
 };
 
+// What the host needs to know of a build, in pinned host memory: the kernels write it there and the host reads it after the wait for
+// the stream it needs anyway. (Five copies into pageable host memory -- level state, node total, depth, equal codes, scene constants --
+// cost the host ~20 us each, one after the other, at the end of every build.)
+struct BuildResults {
+	LevelState level;          // k_collapse_small: the level the round ended at
+	uint32_t tiles_total, depth, equal_codes, pad;
+	DevSceneConsts consts;
+};
+
+__global__ void k_publish(BuildResults *out, const uint32_t *tiles_total, const uint32_t *depth_word, const DevSceneConsts *consts)
+{
+	out->tiles_total = tiles_total ? *tiles_total : 0u;
+	out->depth = depth_word[0];
+	out->equal_codes = depth_word[1];
+	out->consts = *consts;
+}
+
 struct CollapseBufs {
 	int *jobs;                // [job] binary node of the job (current level; LDS inside k_collapse_small)
 	int4 *dec;                // [job] child words, binary references where info says so
@@ -1209,7 +1226,7 @@ __global__ void __launch_bounds__(COLLAPSE_BLOCK) k_collapse_number(CollapseBufs
 // that is already opened (dec/info valid) and hands over one that is opened too, block sums included. Launch 0 of a
 // build opens the root first.
 __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs B, LevelState *ring, uint32_t step, uint32_t max_levels,
-	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root, TopAux aux)
+	const int2 *lr, const uint2 *range, const BinNode *bin, DevTri *tris, DevNode *nodes, uint32_t node_cap, const int *root, TopAux aux, LevelState *host_out)
 {
 	__shared__ uint32_t s_w[COLLAPSE_SMALL / 64];
 	__shared__ int s_ref[COLLAPSE_SMALL * 4];
@@ -1262,7 +1279,10 @@ __global__ void __launch_bounds__(COLLAPSE_SMALL) k_collapse_small(CollapseBufs 
 		// invalidated the L2 at every level: ~25 us per level, a fifth of a 1M-triangle build.
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) ring[(step + 1u) % COLLAPSE_RING] = L;
+	if (threadIdx.x == 0) {
+		ring[(step + 1u) % COLLAPSE_RING] = L;
+		if (host_out) *host_out = L;              // (pinned host memory: the last launch of a round)
+	}
 }
 
 // The tile-local collapse: a SMALL workgroup per refit tile turns the tile's forest of finished binary subtrees into
@@ -1813,6 +1833,7 @@ struct Workspace {
 	                                  // them with every blocking stream of the host), one at a time (the mutex: they share the workspace)
 	hipStream_t side = nullptr;       // tile mode: the per-tile node counts and their prefix sums run here, beside the collapse of the
 	hipEvent_t fork = nullptr, join = nullptr;      // nodes above the tiles (a string of small launches that leaves the GPU mostly idle)
+	struct BuildResults *h_results = nullptr;       // pinned: what a build brings home (kernels write it; the host reads it after its one wait)
 };
 Workspace g_workspace[RTK_MAX_DEVICES];
 
@@ -1995,6 +2016,13 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	}
 	Arena ar = { ws.base, ws.cap, 0 };
 	if (!ws.stream && hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking) != hipSuccess) { ws.stream = nullptr; rtk_set_error("device build: hipStreamCreate failed"); return nullptr; }
+	if (!ws.h_results && hipHostMalloc(reinterpret_cast<void **>(&ws.h_results), sizeof(BuildResults), hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		ws.h_results = nullptr;
+		rtk_set_error("device build: no pinned host memory for the build's results");
+		return nullptr;
+	}
+	BuildResults *const results = ws.h_results;
 	const hipStream_t bs = ws.stream;
 	// a mesh that already lives in device memory was written by the caller's own work, possibly still in flight on the NULL
 	// stream or a blocking stream: that work is waited for here (a build stream of our own does not order itself behind it)
@@ -2211,7 +2239,9 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	static_assert(sizeof(DevNode) == 128, "the carving above: n / 2 * 148 + 8 n + 4 n + padding <= 128 n");
 	uint32_t *d_tile_nroots = ar.take<uint32_t>(num_tiles + 1u);
 	if (hipMemsetAsync(d_depth_word, 0, 16, bs) != hipSuccess) return fail("memset");
-	if (tile_mode && rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();    // (cleared before the second stream forks off: the callee's error text stands)
+	// (the scene's constants block: allocated and cleared here, not between the collapse and the last kernel -- a hipMalloc there was 40 us
+	// in which the GPU waited; in tile mode also before the second stream forks off. The callee's error text stands.)
+	if (rtk_scene_consts(ds, bs) != RTK_AMD_OK) return give_up();
 	// topology and boxes in one bottom-up pass (no separate tree-building kernel), then the nodes that cross tile borders
 	hipLaunchKernelGGL(k_refit_tile, dim3(num_tiles), dim3(REFIT_BLOCK), 0, bs, d_tris, (int)n, keys, d_lr, d_range,
 		d_bin, d_climbers, d_half, d_climb_idx, d_tile_nclimb, d_root, bp, d_area, d_depth_word + 1, tile_mode ? d_root_list : (int *)nullptr,
@@ -2267,17 +2297,17 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		for (uint64_t c = COLLAPSE_SMALL_JOBS; c < jobs_hint; c *= 4) big_levels++;
 		uint32_t step = 0;
 		for (unsigned round = 0;; round++) {
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, top_aux);
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, top_aux, (LevelState *)nullptr);
 			for (unsigned k = 0; k < big_levels; k++) {
 				// number the level of ring entry `step` (-> entry step + 1: the next level, not opened yet), then open that
 				hipLaunchKernelGGL(k_collapse_number, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, target, cap);
 				step++;
 				hipLaunchKernelGGL(k_collapse_open, dim3(big_blocks), dim3(COLLAPSE_BLOCK), 0, bs, cb, d_ring, step, d_lr, d_range, d_bin, d_tris, target, cap, top_aux);
 			}
-			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, top_aux);
-			if (hipGetLastError() != hipSuccess ||
-				hipMemcpyAsync(&h_state, d_ring + step % COLLAPSE_RING, sizeof(h_state), hipMemcpyDeviceToHost, bs) != hipSuccess ||
-				hipStreamSynchronize(bs) != hipSuccess) return false;
+			// (the level the round ends at goes straight into pinned host memory)
+			hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(COLLAPSE_SMALL), 0, bs, cb, d_ring, step++, 16u, d_lr, d_range, d_bin, d_tris, target, cap, d_root, top_aux, &results->level);
+			if (hipGetLastError() != hipSuccess || hipStreamSynchronize(bs) != hipSuccess) return false;
+			memcpy(&h_state, const_cast<const LevelState *>(&results->level), sizeof(h_state));
 			if (h_state.count == 0) return true;
 			if (round > 4096) return false;
 			big_levels = 4;
@@ -2310,12 +2340,12 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 			}
 			hipLaunchKernelGGL(k_top_finish, dim3((top_nodes + 255u) / 256u), dim3(256), 0, bs, d_nodes_tmp, d_top_refs, d_top_level, top_nodes, d_tile_base + num_tiles, d_root_info,
 				d_nodes_, d_qnodes_, (uint32_t)node_cap, consts, d_depth_word);
-			if (hipGetLastError() != hipSuccess ||
-				hipMemcpyAsync(&h_tail[0], d_tile_base + num_tiles, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
-				hipMemcpyAsync(&h_tail[1], d_depth_word, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
-				hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess ||
-				hipMemcpyAsync(&ds->consts_readback, consts, sizeof(DevSceneConsts), hipMemcpyDeviceToHost, bs) != hipSuccess ||
-				hipStreamSynchronize(bs) != hipSuccess) return fail("tile collapse");
+			hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, bs, results, d_tile_base + num_tiles, d_depth_word, consts);
+			if (hipGetLastError() != hipSuccess || hipStreamSynchronize(bs) != hipSuccess) return fail("tile collapse");
+			h_tail[0] = results->tiles_total;
+			h_tail[1] = results->depth;
+			h_equal_codes = results->equal_codes;
+			ds->consts_readback = results->consts;
 #ifdef RTK_TILE_PHASES
 			{
 				unsigned long long h[8] = {}, z[8] = {};
@@ -2380,11 +2410,18 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 		ds->view.nodes = d_nodes_;
 		ds->view.num_nodes = total_nodes;
 		// compressed nodes beside the exact ones (and, if the collapse had to go through the workspace, the exact ones out of it)
-		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap)) != RTK_AMD_OK) return give_up();
+		DevSceneConsts *consts = const_cast<DevSceneConsts *>(ds->view.consts);
+		if (tile_mode && hipMemsetAsync(consts, 0, sizeof(DevSceneConsts), bs) != hipSuccess) return fail("memset");     // (the way back from tile mode: its kernels have counted in there)
+		if (rtk_quantize_nodes(ds, bs, in_place ? nullptr : d_nodes_tmp, (DevNodeQ *)(d_nodes_ + node_cap), 0.0f, 0xffffffffu, true, false) != RTK_AMD_OK) return give_up();
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, bs, results, (const uint32_t *)nullptr, d_depth_word, consts);
+		if (hipGetLastError() != hipSuccess) return fail("publish launch");
 	}
 	ds->total_bytes += node_cap * (sizeof(DevNode) + sizeof(DevNodeQ));
-	if (!tiles_done && hipMemcpyAsync(&h_equal_codes, d_depth_word + 1, 4, hipMemcpyDeviceToHost, bs) != hipSuccess) return fail("copy");
 	if (hipStreamSynchronize(bs) != hipSuccess || (side_busy && hipStreamSynchronize(ws.side) != hipSuccess)) return fail("sync");   // the workspace is handed back below
+	if (!tiles_done) {
+		h_equal_codes = results->equal_codes;
+		ds->consts_readback = results->consts;
+	}
 	rtk_quantize_finish(ds);
 
 	ds->view.tris = d_tris;

@@ -180,7 +180,7 @@ rtk_dev_scene *rtk_dev_scene_from_host_bvh(const HostBvh &h);
 // only_first: finish just the first so many nodes (the device build's tile collapse has finished the others itself);
 // keep_consts: the constants block is already set up (rtk_scene_consts) and holds counts that must survive.
 int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src = nullptr, DevNodeQ *dst = nullptr, float bound_hint = 0.0f,
-	uint32_t only_first = 0xffffffffu, bool keep_consts = false);   // (bound_hint: 0 = none; the floor of 1 is applied inside)
+	uint32_t only_first = 0xffffffffu, bool keep_consts = false, bool readback = true);   // (bound_hint: 0 = none; the floor of 1 is applied inside; readback: enqueue the copy of the constants to the host -- the device build brings them home with its other results)
 int rtk_scene_consts(rtk_dev_scene *ds, hipStream_t stream);
 void rtk_quantize_finish(rtk_dev_scene *ds);   // after that stream has been synchronised
 

@@ -44,7 +44,7 @@ int rtk_scene_consts(rtk_dev_scene *ds, hipStream_t stream)
 	return RTK_AMD_OK;
 }
 
-int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst, float bound_hint, uint32_t only_first, bool keep_consts)
+int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src, DevNodeQ *dst, float bound_hint, uint32_t only_first, bool keep_consts, bool readback)
 {
 	const uint32_t n = ds->view.num_nodes < only_first ? ds->view.num_nodes : only_first;
 	void *p = dst;
@@ -61,7 +61,7 @@ int rtk_quantize_nodes(rtk_dev_scene *ds, hipStream_t stream, const DevNode *src
 	RTK_HIP_CHECK(hipGetLastError(), RTK_AMD_ERR_HIP);
 	ds->view.qnodes = (const DevNodeQ *)p;
 	// the misfit count comes back with the caller's own synchronisation of `stream` (rtk_quantize_finish)
-	RTK_HIP_CHECK(hipMemcpyAsync(&ds->consts_readback, consts, sizeof(DevSceneConsts), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
+	if (readback) RTK_HIP_CHECK(hipMemcpyAsync(&ds->consts_readback, consts, sizeof(DevSceneConsts), hipMemcpyDeviceToHost, stream), RTK_AMD_ERR_HIP);
 	return RTK_AMD_OK;
 }
 
