@@ -1911,7 +1911,10 @@ static rtk_dev_scene *build_impl(const rtk_scene_desc *desc, uint32_t force_bits
 	const auto t_begin = std::chrono::steady_clock::now();
 	const bool timing = getenv("RTK_AMD_BUILD_TIMING") != nullptr;
 	auto t_last = t_begin;
+	// RTK_AMD_BUILD_HOSTTIME=1: where the HOST is when (no synchronisation: how far ahead of the GPU the enqueueing thread runs)
+	const bool host_time = getenv("RTK_AMD_BUILD_HOSTTIME") && atoi(getenv("RTK_AMD_BUILD_HOSTTIME")) != 0;
 	auto stage = [&](const char *name) {
+		if (host_time) fprintf(stderr, "rtk_amd build host: %-10s at %8.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 		if (!timing) return;
 		(void)hipDeviceSynchronize();
 		const auto now = std::chrono::steady_clock::now();
