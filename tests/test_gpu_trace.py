@@ -327,6 +327,13 @@ def test_any_hit_on_an_image_takes_the_packet_kernels(api, scene2):
     rec = ds.trace(frame, opts=opts, full=False)
     assert 0.2 < occ_packets.mean() < 0.95
     assert (occ_packets == occ_lanes).all() and (occ_packets == (rec["prim"] != 0xFFFFFFFF)).all()
+    # rays full of special values (zero and denormal direction components, empty and reversed intervals, NaN min_t, ...) as an "image":
+    # whatever the packet kernels do with them (most tiles are handed back), the flags are the per-lane kernel's
+    exotic = np.tile(synth.rays_exotic(2048), 4)
+    assert len(exotic) == 128 * 64
+    e_opts = api.make_opts(image=(128, 64))
+    assert (ds.trace_any(exotic, opts=e_opts) == ds.trace_any(exotic, opts=api.make_opts(no_detect=True))).all()
+    assert (ds.trace_any(exotic, opts=e_opts) == (ds.trace(exotic, opts=e_opts, full=False)["prim"] != 0xFFFFFFFF)).all()
     ragged = synth.rays_pinhole(200, 96)                               # not whole blocks: per lane, same answers as closest hit
     assert (ds.trace_any(ragged, opts=api.make_opts(image=(200, 96))) == (ds.trace(ragged, full=False)["prim"] != 0xFFFFFFFF)).all()
 
